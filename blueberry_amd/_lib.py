@@ -1,0 +1,107 @@
+"""ctypes binding of libblueberry_hip.so (C-ABI: include/blueberry_hip.h).
+
+There is deliberately NO fallback here: if the shared library is missing, or
+there is no usable MI355X, every compute call raises.  The CPU oracle under
+oracle/ is test infrastructure and is never imported from this package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libblueberry_hip.so")
+
+BB_OK, BB_ERR_INVALID, BB_ERR_HIP, BB_ERR_STATE, BB_ERR_NOMEM = 0, 1, 2, 3, 4
+BB_F32, BB_F64 = 0, 1
+BB_KIND_WISH, BB_KIND_COUNTS = 0, 1
+
+c_i32, c_i64, c_dbl = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+p_i32, p_i64, p_dbl = (ctypes.POINTER(c_i32), ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl))
+c_int, c_void_p = ctypes.c_int, ctypes.c_void_p
+
+
+class LayoutInfo(ctypes.Structure):
+    """struct bb_layout_info (include/blueberry_hip.h)."""
+    _fields_ = [(name, c_i64) for name in (
+        "n_bins", "n_pad", "vw", "rows_per_unit", "units_per_tile", "n_blocks", "n_tiles",
+        "n_units")]
+
+    def as_dict(self):
+        return {name: int(getattr(self, name)) for name, _ in self._fields_}
+
+
+# name -> (restype, argtypes); every symbol include/blueberry_hip.h declares
+SIGNATURES = {
+    "bb_version": (c_int, []),
+    "bb_last_error": (ctypes.c_char_p, []),
+    "bb_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "bb_band_count": (c_int, [p_dbl, c_i64, c_i32, c_i32, c_int, p_i64]),
+    "bb_band_count_rows": (c_int, [p_dbl, c_i64, c_i32, c_i32, c_i64, c_i64, c_int, p_i64]),
+    "bb_layout_dense_info": (c_int, [c_i64, c_int, ctypes.POINTER(LayoutInfo)]),
+    "bb_layout_dense_tiles": (c_int, [c_i64, c_int, p_i32, p_i32, c_i64]),
+    "bb_layout_rank_units": (c_int, [c_i64, c_int, c_int, p_i64, p_i64]),
+    "bb_solver_create": (c_int, [ctypes.POINTER(c_void_p), c_i64, c_int, c_int, c_int, c_int,
+                                 p_i32, p_i32, c_i64]),
+    "bb_solver_destroy": (c_int, [c_void_p]),
+    "bb_solver_set_stream": (c_int, [c_void_p, c_void_p]),
+    "bb_solver_layout": (c_int, [c_void_p, ctypes.POINTER(LayoutInfo), p_i64, p_i64]),
+    "bb_solver_set_wish_dense": (c_int, [c_void_p, p_dbl, c_i64, c_int, c_dbl]),
+    "bb_solver_set_wish_from_coords": (c_int, [c_void_p, p_dbl]),
+    "bb_solver_set_coords": (c_int, [c_void_p, p_dbl]),
+    "bb_solver_get_coords": (c_int, [c_void_p, p_dbl]),
+    "bb_solver_iterate": (c_int, [c_void_p, c_i64, c_dbl]),
+    "bb_solver_grad": (c_int, [c_void_p]),
+    "bb_solver_apply": (c_int, [c_void_p, c_dbl]),
+    "bb_solver_exchange_size": (c_int, [c_void_p, p_i64]),
+    "bb_solver_get_exchange_buffer": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    "bb_solver_set_exchange_buffer": (c_int, [c_void_p, c_void_p]),
+    "bb_solver_stress": (c_int, [c_void_p, p_dbl]),
+    "bb_solver_get_stress_history": (c_int, [c_void_p, p_dbl, c_i64, p_i64]),
+    "bb_solver_sync": (c_int, [c_void_p]),
+    "bb_solver_set_timing": (c_int, [c_void_p, c_int]),
+    "bb_solver_get_timing": (c_int, [c_void_p, p_dbl, p_dbl, p_i64]),
+    "bb_solver_traffic": (c_int, [c_void_p, p_i64, p_i64]),
+    "bb_contactmap_scatter": (c_int, [p_dbl, c_i64, c_i32, p_dbl, c_i64, c_int]),
+    "bb_contactmap_normalize": (c_int, [p_dbl, c_i64, p_dbl, p_dbl, c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "blueberry_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as "
+            "g; g.build()'` (or ./build.sh) at the repository root. There is no CPU fallback."
+            % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error():
+    msg = load().bb_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc, what=""):
+    """Turn a BB_ERR_* status into the Python exception the host API documents."""
+    if rc == BB_OK:
+        return
+    msg = last_error() or ("%s failed (status %d)" % (what, rc))
+    if rc == BB_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == BB_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def as_f64_ptr(arr):
+    return arr.ctypes.data_as(p_dbl)

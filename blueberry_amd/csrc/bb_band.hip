@@ -1,0 +1,127 @@
+// bb_band.hip -- K1: count_band_regions on the GPU.
+//
+// Replaces the O(N^2/2) `nogil` double loop at reference
+// blueberry/blueberry.pyx:77-91:
+//     for i in range(n): for j in range(i):
+//         if LOW <= regions[i] - regions[j] <= HIGH: t += 1
+// Exact: fp64 subtract, two fp64 compares against the int thresholds promoted
+// to double (pyx:82), integer sum.  The input is O(N), so this kernel is
+// issue-bound, not HBM-bound; it is the structural template for the pair
+// tiling (j-chunk staged in LDS N-body style, one thread per i, wavefront
+// shuffle reduction, one integer atomic per workgroup).
+#include "bb_common.h"
+
+namespace {
+
+constexpr int kIB = 256;   // rows (i) per workgroup: one per thread
+constexpr int kJC = 2048;  // columns (j) staged in LDS per workgroup: 16 KiB
+
+__global__ __launch_bounds__(kIB) void band_count_kernel(const double *__restrict__ r, int64_t n,
+                                                         double lo, double hi, int64_t i_begin,
+                                                         int64_t i_end,
+                                                         unsigned long long *__restrict__ out) {
+    __shared__ double sh[kJC];
+    const int tid = threadIdx.x;
+    const int64_t i0 = i_begin + (int64_t)blockIdx.y * kIB;
+    const int64_t j0 = (int64_t)blockIdx.x * kJC;
+    const int64_t i_top = i0 + kIB < i_end ? i0 + kIB : i_end;  // one past the last row here
+    // columns that can pair with some row of this block: j <= (i_top - 1) - 1
+    int64_t jn = (i_top - 1) - j0;
+    if (jn > kJC) jn = kJC;
+    if (jn <= 0) return;  // workgroup-uniform: every j of this chunk >= every i of this block
+
+    for (int k = tid; k < jn; k += kIB) sh[k] = r[j0 + k];
+    __syncthreads();
+
+    const int64_t i = i0 + tid;
+    const bool row_ok = i < i_end;
+    const double ri = row_ok ? r[i] : 0.0;
+    unsigned int cnt = 0;  // per-thread hits (<= kJC)
+    if (j0 + jn <= i0) {
+        // chunk entirely below the diagonal for every row of the block: j < i holds
+#pragma unroll 8
+        for (int k = 0; k < (int)jn; ++k) {
+            const double d = ri - sh[k];
+            cnt += (row_ok && lo <= d && d <= hi) ? 1u : 0u;
+        }
+    } else {
+        const int64_t lim = i - j0;  // j0 + k < i  <=>  k < lim
+#pragma unroll 8
+        for (int k = 0; k < (int)jn; ++k) {
+            const double d = ri - sh[k];
+            cnt += (row_ok && k < lim && lo <= d && d <= hi) ? 1u : 0u;
+        }
+    }
+    // wavefront shuffle reduction, then one integer atomic per workgroup
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    __shared__ unsigned int wsum[kIB / 64];
+    if ((tid & 63) == 0) wsum[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long tot = 0;
+        for (int w = 0; w < kIB / 64; ++w) tot += wsum[w];
+        if (tot) atomicAdd(out, tot);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bb_band_count_rows(const double *regions, int64_t n, int32_t low, int32_t high,
+                       int64_t i_begin, int64_t i_end, int device, int64_t *count) {
+    BB_REQUIRE(count != nullptr, "bb_band_count: count is NULL");
+    *count = 0;
+    BB_REQUIRE(n >= 0, "bb_band_count: n < 0");
+    BB_REQUIRE(n <= (int64_t)0x7fffffff, "bb_band_count: n exceeds the reference's C int range");
+    BB_REQUIRE(regions != nullptr || n == 0, "bb_band_count: regions is NULL");
+    int rc = bb::use_device(device);
+    if (rc != BB_OK) return rc;
+    if (i_begin < 0) i_begin = 0;
+    if (i_end > n) i_end = n;
+    if (n < 2 || i_begin >= i_end || i_end < 2) return BB_OK;  // no (i, j < i) pair
+
+    double *d_r = nullptr;
+    unsigned long long *d_out = nullptr;
+    hipError_t e = hipMalloc((void **)&d_r, (size_t)n * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        hipFree(d_r);
+        return bb::fail(BB_ERR_NOMEM, std::string("bb_band_count: hipMalloc: ") + hipGetErrorString(e));
+    }
+    hipStream_t st = nullptr;
+    e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_r, regions, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, sizeof(unsigned long long), st);
+    if (e == hipSuccess) {
+        const int64_t rows = i_end - i_begin;
+        const dim3 grid((unsigned)((i_end - 1 + kJC - 1) / kJC), (unsigned)((rows + kIB - 1) / kIB));
+        if (grid.y > 65535u) {
+            e = hipErrorInvalidValue;
+        } else {
+            hipLaunchKernelGGL(band_count_kernel, grid, dim3(kIB), 0, st, d_r, n, (double)low,
+                               (double)high, i_begin, i_end, d_out);
+            e = hipGetLastError();
+        }
+    }
+    unsigned long long host_out = 0;
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(&host_out, d_out, sizeof(host_out), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (st) hipStreamDestroy(st);
+    hipFree(d_r);
+    hipFree(d_out);
+    if (e != hipSuccess)
+        return bb::fail(BB_ERR_HIP, std::string("bb_band_count: ") + hipGetErrorString(e));
+    *count = (int64_t)host_out;
+    return BB_OK;
+}
+
+int bb_band_count(const double *regions, int64_t n, int32_t low, int32_t high, int device,
+                  int64_t *count) {
+    return bb_band_count_rows(regions, n, low, high, 0, n, device, count);
+}
+
+}  // extern "C"

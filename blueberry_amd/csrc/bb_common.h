@@ -1,0 +1,43 @@
+// bb_common.h -- internal helpers shared by the translation units of
+// libblueberry_hip.so (error state, HIP status checks, layout arithmetic).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "blueberry_hip.h"
+
+namespace bb {
+
+// Thread-local last-error message behind bb_last_error().
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+#define BB_HIP_CHECK(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess)                                                           \
+            return ::bb::fail(BB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define BB_REQUIRE(cond, msg)                                   \
+    do {                                                        \
+        if (!(cond)) return ::bb::fail(BB_ERR_INVALID, (msg));  \
+    } while (0)
+
+// ---- layout constants (docs/SPEC.md 3) -----------------------------------
+// A wave row is 64 lanes x 16 B = 1 KiB: 256 fp32 or 128 fp64 columns.
+constexpr int kRowsPerUnit = 8;
+constexpr int kWaveRowBytes = 1024;
+constexpr int kUnitBytes = kRowsPerUnit * kWaveRowBytes;  // 8 KiB
+
+inline int64_t elem_size(int dtype) { return dtype == BB_F64 ? 8 : 4; }
+inline int64_t tile_width(int dtype) { return kWaveRowBytes / elem_size(dtype); }
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// Select the device, failing loudly when there is none.
+int use_device(int device);
+
+}  // namespace bb

@@ -1,0 +1,1063 @@
+// bb_solver.hip -- the 3D-structure solver of libblueberry_hip.so: stress +
+// gradient over the packed upper triangle of the wish-distance matrix, the
+// deterministic partial reduce, and the coordinate update.  gfx950 only.
+//
+// Specification: docs/SPEC.md (build-authored; the reference has no solver,
+// SURVEY.md section 0).  Data layout and kernel design: DESIGN.md 3-4.
+//
+// Layout recap (SPEC 3).  The matrix is cut into vw x vw tiles (vw = 1 KiB of
+// elements: 256 fp32 / 128 fp64), upper-triangular tiles only, ordered
+// column-strip major (J, then I).  A tile is vw/8 "units"; a unit is 8 matrix
+// rows x vw columns = 8 KiB, row-major, so one wave reads one matrix row of a
+// unit with one 16-B-per-lane load and lane l always owns the same VPL columns
+// of the strip.  That makes the column side of the symmetric update
+// register-resident for a whole strip sweep (no cross-lane traffic), and only
+// the row side needs one DPP wave reduction per matrix row.
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "bb_common.h"
+
+namespace {
+
+using bb::kRowsPerUnit;
+
+// --------------------------------------------------------------------------
+// type traits
+// --------------------------------------------------------------------------
+template <typename T>
+struct Traits;
+template <>
+struct Traits<float> {
+    using Vec = float4;
+    static constexpr int VPL = 4;  // elements per lane per 16-B load
+    static constexpr int VW = 256;
+    static __device__ __forceinline__ float eps2() { return 1e-30f; }
+};
+template <>
+struct Traits<double> {
+    using Vec = double2;
+    static constexpr int VPL = 2;
+    static constexpr int VW = 128;
+    static __device__ __forceinline__ double eps2() { return 1e-300; }
+};
+
+template <int C>
+__device__ __forceinline__ float elem(const float4 &v) {
+    if constexpr (C == 0) return v.x;
+    if constexpr (C == 1) return v.y;
+    if constexpr (C == 2) return v.z;
+    return v.w;
+}
+template <int C>
+__device__ __forceinline__ double elem(const double2 &v) {
+    if constexpr (C == 0) return v.x;
+    return v.y;
+}
+
+// --------------------------------------------------------------------------
+// cross-lane helpers (wave64, DPP; no LDS)
+// --------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_get(double v) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes; the total is valid in lanes 48..63 (we read lane 63).
+// Fixed tree => bitwise deterministic.
+template <typename T>
+__device__ __forceinline__ T wave_sum_hi(T v) {
+    v += dpp_get<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += dpp_get<0x141, 0xF>(v);  // row_half_mirror
+    v += dpp_get<0x140, 0xF>(v);  // row_mirror
+    v += dpp_get<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
+    v += dpp_get<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3
+    return v;
+}
+
+// Value of `v` in lane `l` (compile-time l) as a wave-uniform scalar.
+__device__ __forceinline__ float lane_value(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ double lane_value(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// Branch-free "lane 63 only" store of a row's three sums through a raw buffer
+// descriptor: every other lane carries an out-of-range offset and the
+// hardware range check drops its store.  (An `if (lane == 63)` around a plain
+// store splits the unit into basic blocks, and LLVM then sinks all column-side
+// accumulation below the last of them, spilling 32 pairs of forces.)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kDropOffset = 0x80000000u;
+
+__device__ __forceinline__ void store_row3(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, float a,
+                                           float b, float c) {
+    u32x3 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c)};
+    __builtin_amdgcn_raw_buffer_store_b96(v, rsrc, voff, 0, 0);
+}
+__device__ __forceinline__ void store_row3(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, double a,
+                                           double b, double c) {
+    u32x4 v = {(unsigned)__double2loint(a), (unsigned)__double2hiint(a),
+               (unsigned)__double2loint(b), (unsigned)__double2hiint(b)};
+    u32x2 w = {(unsigned)__double2loint(c), (unsigned)__double2hiint(c)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, voff + 16, 0, 0);
+}
+
+// --------------------------------------------------------------------------
+// stress + gradient kernel
+// --------------------------------------------------------------------------
+template <typename T>
+struct GradParams {
+    const T *__restrict__ units;             // this rank's units, 8*VW elements each
+    const T *__restrict__ X;                 // (n_pad, 3)
+    const int2 *__restrict__ udesc;          // per local unit: {i0, j0}
+    const int64_t *__restrict__ wave_begin;  // n_waves + 1 local unit indices
+    const int32_t *__restrict__ wave_slot;   // first column-partial slot of each wave
+    T *__restrict__ rowpart;                 // 24 elements per unit, tile-aligned base
+    T *__restrict__ colpart;                 // 3*VW elements per slot
+    double *__restrict__ stresspart;         // one per wave
+    int64_t row_shift;                       // u_begin - t_first * units_per_tile
+};
+
+// Pair math for one matrix row of a unit: VPL pairs per lane.
+template <typename T, int C>
+__device__ __forceinline__ void pair_step(const typename Traits<T>::Vec &drow, T xi, T yi, T zi,
+                                          const T (&xj)[Traits<T>::VPL][3],
+                                          T (&gc)[Traits<T>::VPL][3], T &gx, T &gy, T &gz, T &s) {
+    const T delta = elem<C>(drow);
+    const T dx = xi - xj[C][0], dy = yi - xj[C][1], dz = zi - xj[C][2];
+    T d2 = fma(dx, dx, fma(dy, dy, dz * dz));
+    d2 = d2 < Traits<T>::eps2() ? Traits<T>::eps2() : d2;
+    T rinv, dist;
+    if constexpr (sizeof(T) == 4) {
+        rinv = __builtin_amdgcn_rsqf(d2);
+        dist = d2 * rinv;
+    } else {
+        dist = sqrt(d2);
+        rinv = 1.0 / dist;
+    }
+    const T res = delta > T(0) ? dist - delta : T(0);
+    s = fma(res, res, s);
+    const T coef = res * rinv;  // (d - delta) / d ; the factor 2 is applied in the reduce
+    const T fx = coef * dx, fy = coef * dy, fz = coef * dz;
+    gx += fx; gy += fy; gz += fz;
+    gc[C][0] -= fx; gc[C][1] -= fy; gc[C][2] -= fz;
+}
+
+// One unit (8 matrix rows).  Row r of the CURRENT unit is consumed from d[r],
+// then d[r] is immediately refilled with row r of the NEXT unit, so 8 KiB per
+// wave stay in flight with a single 8-row register buffer.
+template <typename T>
+__device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[kRowsPerUnit], T xrow,
+                                             const typename Traits<T>::Vec *__restrict__ next,
+                                             const T (&xj)[Traits<T>::VPL][3],
+                                             T (&gc)[Traits<T>::VPL][3], double &stress,
+                                             __amdgpu_buffer_rsrc_t row_rsrc, unsigned row_voff) {
+    constexpr int VPL = Traits<T>::VPL;
+    T s = T(0);
+#pragma unroll
+    for (int r = 0; r < kRowsPerUnit; ++r) {
+        const T xi = lane_value(xrow, 3 * r), yi = lane_value(xrow, 3 * r + 1),
+                zi = lane_value(xrow, 3 * r + 2);
+        T gx = T(0), gy = T(0), gz = T(0);
+        pair_step<T, 0>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
+        pair_step<T, 1>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
+        if constexpr (VPL == 4) {
+            pair_step<T, 2>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
+            pair_step<T, 3>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
+        }
+        d[r] = next[r * 64];
+        gx = wave_sum_hi(gx);
+        gy = wave_sum_hi(gy);
+        gz = wave_sum_hi(gz);
+        // one 3-element store per matrix row, from the lane holding the sums
+        store_row3(row_rsrc, row_voff + r * 3 * (unsigned)sizeof(T), gx, gy, gz);
+        // keep the rows in program order: otherwise the scheduler interleaves all
+        // eight rows for ILP and spills
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    stress += (double)s;
+}
+
+template <typename T>
+__device__ __forceinline__ const typename Traits<T>::Vec *unit_ptr(const T *__restrict__ units,
+                                                                   int64_t ul, int lane) {
+    using Vec = typename Traits<T>::Vec;
+    return reinterpret_cast<const Vec *>(units) + ul * (kRowsPerUnit * 64) + lane;
+}
+
+// coordinates of a unit's 8 rows: 24 consecutive elements, one per lane
+template <typename T>
+__device__ __forceinline__ T load_xrow(const T *__restrict__ X, int i0, int lane) {
+    return X[(int64_t)i0 * 3 + (lane < 3 * kRowsPerUnit ? lane : 0)];
+}
+
+template <typename T>
+__device__ __forceinline__ void load_strip(T (&xj)[Traits<T>::VPL][3], const T *__restrict__ X,
+                                           int j0, int lane) {
+    using Vec = typename Traits<T>::Vec;
+    constexpr int VPL = Traits<T>::VPL;
+    // 3*VPL consecutive elements (48 B) per lane
+    const Vec *p = reinterpret_cast<const Vec *>(X + ((int64_t)j0 + (int64_t)lane * VPL) * 3);
+    Vec a = p[0], b = p[1], c = p[2];
+    if constexpr (VPL == 4) {
+        xj[0][0] = a.x; xj[0][1] = a.y; xj[0][2] = a.z;
+        xj[1][0] = a.w; xj[1][1] = b.x; xj[1][2] = b.y;
+        xj[2][0] = b.z; xj[2][1] = b.w; xj[2][2] = c.x;
+        xj[3][0] = c.y; xj[3][1] = c.z; xj[3][2] = c.w;
+    } else {
+        xj[0][0] = a.x; xj[0][1] = a.y; xj[0][2] = b.x;
+        xj[1][0] = b.y; xj[1][1] = c.x; xj[1][2] = c.y;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_strip(const T (&gc)[Traits<T>::VPL][3],
+                                            T *__restrict__ slot, int lane) {
+    using Vec = typename Traits<T>::Vec;
+    constexpr int VPL = Traits<T>::VPL;
+    Vec *p = reinterpret_cast<Vec *>(slot + (int64_t)lane * VPL * 3);
+    if constexpr (VPL == 4) {
+        p[0] = make_float4(gc[0][0], gc[0][1], gc[0][2], gc[1][0]);
+        p[1] = make_float4(gc[1][1], gc[1][2], gc[2][0], gc[2][1]);
+        p[2] = make_float4(gc[2][2], gc[3][0], gc[3][1], gc[3][2]);
+    } else {
+        p[0] = make_double2(gc[0][0], gc[0][1]);
+        p[1] = make_double2(gc[0][2], gc[1][0]);
+        p[2] = make_double2(gc[1][1], gc[1][2]);
+    }
+}
+
+// One wave = one contiguous chunk of units; 4 independent waves per workgroup.
+// No LDS, no barriers, no atomics: results are bitwise reproducible.
+template <typename T>
+__global__ __launch_bounds__(256, 4) void stress_grad_kernel(GradParams<T> p) {
+    using Vec = typename Traits<T>::Vec;
+    constexpr int VPL = Traits<T>::VPL;
+    constexpr int VW = Traits<T>::VW;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int64_t ua = p.wave_begin[w], ub = p.wave_begin[w + 1];
+    double stress = 0.0;
+
+    if (ua < ub) {
+        int slot = p.wave_slot[w];
+        T xj[VPL][3], gc[VPL][3];
+        Vec d[kRowsPerUnit];
+
+        int2 dc = p.udesc[ua];                             // current unit
+        int2 dn = p.udesc[ua + 1 < ub ? ua + 1 : ub - 1];  // next unit
+        int curj = dc.y;
+        load_strip<T>(xj, p.X, curj, lane);
+#pragma unroll
+        for (int c = 0; c < VPL; ++c) gc[c][0] = gc[c][1] = gc[c][2] = T(0);
+        {
+            const Vec *first = unit_ptr<T>(p.units, ua, lane);
+#pragma unroll
+            for (int r = 0; r < kRowsPerUnit; ++r) d[r] = first[r * 64];
+        }
+        T xr = load_xrow<T>(p.X, dc.x, lane);
+        // this wave's row partials: 24 elements per unit
+        constexpr unsigned kRowBytes = 3 * kRowsPerUnit * sizeof(T);
+        const __amdgpu_buffer_rsrc_t row_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.rowpart + (ua + p.row_shift) * (3 * kRowsPerUnit), 0, (int)((ub - ua) * kRowBytes),
+            0x00020000);
+
+        for (int64_t u = ua; u < ub; ++u) {
+            // the wave's last unit "prefetches" itself: harmless, stays in bounds
+            const int64_t un = u + 1 < ub ? u + 1 : ub - 1;
+            const T xrn = load_xrow<T>(p.X, dn.x, lane);
+            const int2 dnn = p.udesc[u + 2 < ub ? u + 2 : ub - 1];
+            if (dc.y != curj) {  // wave-uniform: the sweep enters a new column strip
+                store_strip<T>(gc, p.colpart + (int64_t)slot * (3 * VW), lane);
+                ++slot;
+                curj = dc.y;
+                load_strip<T>(xj, p.X, curj, lane);
+#pragma unroll
+                for (int c = 0; c < VPL; ++c) gc[c][0] = gc[c][1] = gc[c][2] = T(0);
+            }
+            const unsigned row_voff = lane == 63 ? (unsigned)(u - ua) * kRowBytes : kDropOffset;
+            process_unit<T>(d, xr, unit_ptr<T>(p.units, un, lane), xj, gc, stress, row_rsrc,
+                            row_voff);
+            xr = xrn;
+            dc = dn;
+            dn = dnn;
+        }
+        store_strip<T>(gc, p.colpart + (int64_t)slot * (3 * VW), lane);
+    }
+
+    // per-wave stress (fixed shuffle tree)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) stress += __shfl_down(stress, off, 64);
+    if (lane == 0) p.stresspart[w] = stress;
+}
+
+// --------------------------------------------------------------------------
+// reduce (+ update) kernel: one workgroup per vw-bin block
+// --------------------------------------------------------------------------
+enum ReduceMode { kReduceApply = 0, kReduceExchange = 1, kReduceStressOnly = 2 };
+
+template <typename T>
+struct ReduceParams {
+    const T *__restrict__ part;              // rowpart | colpart
+    const int64_t *__restrict__ blk_ptr;     // n_blocks + 1
+    const int64_t *__restrict__ blk_chunk;   // element offsets into part
+    const double *__restrict__ stresspart;
+    T *__restrict__ X;                       // apply mode
+    T *__restrict__ exch;                    // exchange mode: [3*n_pad | hi | lo]
+    double *__restrict__ stress_out;         // apply / stress-only: where the stress goes
+    int64_t n_pad;
+    int n_waves;
+    int mode;
+    T lr;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
+    constexpr int CH = 3 * Traits<T>::VW;
+    constexpr int NE = (CH + 255) / 256;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    if (p.mode != kReduceStressOnly) {
+        const int64_t k0 = p.blk_ptr[b], k1 = p.blk_ptr[b + 1];
+        T acc[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) acc[j] = T(0);
+        for (int64_t k = k0; k < k1; ++k) {
+            const T *src = p.part + p.blk_chunk[k];
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int e = tid + 256 * j;
+                if (e < CH) acc[j] += src[e];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int e = tid + 256 * j;
+            if (e < CH) {
+                const T g = T(2) * acc[j];
+                const int64_t o = (int64_t)b * CH + e;
+                if (p.mode == kReduceApply)
+                    p.X[o] -= p.lr * g;
+                else
+                    p.exch[o] = g;
+            }
+        }
+    }
+    if (b == 0) {
+        __shared__ double sh[256];
+        double s = 0.0;
+        for (int i = tid; i < p.n_waves; i += 256) s += p.stresspart[i];
+        sh[tid] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) sh[tid] += sh[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double S = sh[0];
+            if (p.mode == kReduceExchange) {
+                const T hi = (T)S;
+                p.exch[3 * p.n_pad] = hi;
+                p.exch[3 * p.n_pad + 1] = (T)(S - (double)hi);
+            } else {
+                *p.stress_out = S;
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void apply_kernel(T *__restrict__ X, const T *__restrict__ exch,
+                                                    int64_t n3, T lr, double *stress_out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n3) X[e] -= lr * exch[e];
+    if (e == 0 && stress_out) *stress_out = (double)exch[n3] + (double)exch[n3 + 1];
+}
+
+// --------------------------------------------------------------------------
+// packing kernels
+// --------------------------------------------------------------------------
+// staged fp64 rows (row-major, ld = VW) -> units of one run of tiles.
+template <typename T>
+__global__ __launch_bounds__(256) void convert_units_kernel(
+    const double *__restrict__ stage, T *__restrict__ units_out, const int2 *__restrict__ udesc,
+    int64_t ul0, int64_t stage_row0 /* global row of stage row 0 */, int64_t n_bins, int kind,
+    double neg_inv_alpha) {
+    constexpr int VW = Traits<T>::VW;
+    const int64_t ul = ul0 + blockIdx.x;
+    const int2 dsc = udesc[ul];
+    T *out = units_out + ul * (kRowsPerUnit * VW);
+    for (int e = threadIdx.x; e < kRowsPerUnit * VW; e += 256) {
+        const int r = e / VW, c = e % VW;
+        const int64_t i = (int64_t)dsc.x + r, j = (int64_t)dsc.y + c;
+        double v = 0.0;
+        if (j > i && j < n_bins) {
+            v = stage[(i - stage_row0) * VW + c];
+            const bool ok = (v > 0.0) && (v <= 1.7976931348623157e308);  // finite, positive
+            if (!ok)
+                v = 0.0;
+            else if (kind == BB_KIND_COUNTS)
+                v = pow(v, neg_inv_alpha);
+        }
+        out[e] = (T)v;
+    }
+}
+
+// delta_ij = |x*_i - x*_j| generated in place (synthetic inputs).
+template <typename T>
+__global__ __launch_bounds__(256) void gen_units_kernel(const double *__restrict__ xs,
+                                                        T *__restrict__ units_out,
+                                                        const int2 *__restrict__ udesc,
+                                                        int64_t n_bins) {
+    constexpr int VW = Traits<T>::VW;
+    const int64_t ul = blockIdx.x;
+    const int2 dsc = udesc[ul];
+    T *out = units_out + ul * (kRowsPerUnit * VW);
+    for (int e = threadIdx.x; e < kRowsPerUnit * VW; e += 256) {
+        const int r = e / VW, c = e % VW;
+        const int64_t i = (int64_t)dsc.x + r, j = (int64_t)dsc.y + c;
+        double v = 0.0;
+        if (j > i && j < n_bins) {
+            const double dx = xs[3 * i] - xs[3 * j], dy = xs[3 * i + 1] - xs[3 * j + 1],
+                         dz = xs[3 * i + 2] - xs[3 * j + 2];
+            v = sqrt(dx * dx + dy * dy + dz * dz);
+        }
+        out[e] = (T)v;
+    }
+}
+
+template <typename T>
+__global__ void f64_to_T_kernel(const double *__restrict__ in, T *__restrict__ out, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) out[e] = (T)in[e];
+}
+template <typename T>
+__global__ void T_to_f64_kernel(const T *__restrict__ in, double *__restrict__ out, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) out[e] = (double)in[e];
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------
+struct bb_solver {
+    int dtype = BB_F32, device = 0, rank = 0, world = 1;
+    bb_layout_info L{};
+    std::vector<int32_t> tile_I, tile_J;  // global tile list (device order)
+    int64_t u_begin = 0, u_end = 0, n_local = 0;
+    int64_t t_first = 0, n_local_tiles = 0;
+    std::vector<int2> udesc;  // host copy
+
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    void *d_units = nullptr, *d_X = nullptr, *d_part = nullptr, *d_exch = nullptr;
+    bool own_exch = false;
+    int2 *d_udesc = nullptr;
+    int64_t *d_wave_begin = nullptr;
+    int32_t *d_wave_slot = nullptr;
+    double *d_stresspart = nullptr;
+    int64_t *d_blk_ptr = nullptr, *d_blk_chunk = nullptr;
+    double *d_stress_hist = nullptr, *d_stress_scalar = nullptr;
+    double *d_f64_tmp = nullptr;  // (n_pad,3) staging for coordinate I/O
+    int64_t rowpart_elems = 0, colpart_elems = 0;
+    int n_waves = 0, n_slots = 0;
+    int64_t hist_cap = 0, hist_n = 0;
+    bool have_wish = false, have_coords = false, grad_pending = false;
+
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // triples: start, after grad, after reduce
+    size_t ev_used = 0;
+};
+
+namespace {
+
+constexpr int64_t kHistCap = 1 << 20;
+constexpr size_t kMaxTimedLaunches = 4096;
+
+template <typename T>
+int dev_alloc(T **p, int64_t count) {
+    *p = nullptr;
+    if (count <= 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, (size_t)count * sizeof(T));
+    if (e != hipSuccess)
+        return bb::fail(BB_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+    return BB_OK;
+}
+
+#define BB_TRY(expr)                 \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != BB_OK) return _rc; \
+    } while (0)
+
+int waves_per_cu() {
+    const char *e = getenv("BB_WAVES_PER_CU");
+    int v = e ? atoi(e) : 16;
+    if (v < 1) v = 1;
+    if (v > 32) v = 32;
+    return v;
+}
+
+// Build every index the kernels need from (tile list, unit range).
+int build_indices(bb_solver *s) {
+    const int64_t upt = s->L.units_per_tile, vw = s->L.vw;
+    const int64_t ch = 3 * vw;
+    s->n_local = s->u_end - s->u_begin;
+    s->t_first = s->n_local > 0 ? s->u_begin / upt : 0;
+    const int64_t t_last = s->n_local > 0 ? (s->u_end - 1) / upt : -1;
+    s->n_local_tiles = s->n_local > 0 ? t_last - s->t_first + 1 : 0;
+
+    s->udesc.resize((size_t)std::max<int64_t>(s->n_local, 1));
+    for (int64_t ul = 0; ul < s->n_local; ++ul) {
+        const int64_t u = s->u_begin + ul, t = u / upt, sub = u % upt;
+        s->udesc[ul] = make_int2((int)(s->tile_I[t] * vw + sub * kRowsPerUnit),
+                                 (int)(s->tile_J[t] * vw));
+    }
+
+    int cus = 256;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
+    int64_t want = (int64_t)cus * waves_per_cu();
+    int64_t nw = std::max<int64_t>(1, std::min<int64_t>(want, s->n_local));
+    nw = bb::round_up(nw, 4);
+    s->n_waves = (int)nw;
+
+    std::vector<int64_t> wave_begin(nw + 1);
+    std::vector<int32_t> wave_slot(nw);
+    // waves beyond n_local (padding to a multiple of 4) get empty chunks
+    const int64_t active = std::max<int64_t>(1, std::min<int64_t>(want, s->n_local));
+    for (int64_t w = 0; w <= nw; ++w) {
+        const int64_t ww = std::min(w, active);
+        wave_begin[w] = (int64_t)((__int128)s->n_local * ww / active);
+    }
+    // column-partial slots: one per (wave, strip) intersection, in wave order
+    std::vector<int32_t> slot_strip;
+    for (int64_t w = 0; w < nw; ++w) {
+        wave_slot[w] = (int32_t)slot_strip.size();
+        int cur = -1;
+        for (int64_t ul = wave_begin[w]; ul < wave_begin[w + 1]; ++ul) {
+            const int J = s->udesc[ul].y / (int)vw;
+            if (J != cur) {
+                slot_strip.push_back(J);
+                cur = J;
+            }
+        }
+    }
+    s->n_slots = (int)slot_strip.size();
+    s->rowpart_elems = s->n_local_tiles * ch;
+    s->colpart_elems = (int64_t)s->n_slots * ch;
+
+    // reduce CSR: block b <- row chunks of local tiles with I == b, then column slots of strip b
+    const int64_t nb = s->L.n_blocks;
+    std::vector<int64_t> blk_ptr(nb + 1, 0);
+    for (int64_t lt = 0; lt < s->n_local_tiles; ++lt) blk_ptr[s->tile_I[s->t_first + lt] + 1]++;
+    for (int sl = 0; sl < s->n_slots; ++sl) blk_ptr[slot_strip[sl] + 1]++;
+    for (int64_t b = 0; b < nb; ++b) blk_ptr[b + 1] += blk_ptr[b];
+    std::vector<int64_t> blk_chunk((size_t)std::max<int64_t>(blk_ptr[nb], 1));
+    std::vector<int64_t> fill(blk_ptr.begin(), blk_ptr.end() - 1);
+    for (int64_t lt = 0; lt < s->n_local_tiles; ++lt)
+        blk_chunk[fill[s->tile_I[s->t_first + lt]]++] = lt * ch;
+    for (int sl = 0; sl < s->n_slots; ++sl)
+        blk_chunk[fill[slot_strip[sl]]++] = s->rowpart_elems + (int64_t)sl * ch;
+
+    const int64_t es = bb::elem_size(s->dtype);
+    BB_TRY(dev_alloc((char **)&s->d_units, std::max<int64_t>(s->n_local, 1) * bb::kUnitBytes));
+    BB_TRY(dev_alloc((char **)&s->d_X, s->L.n_pad * 3 * es));
+    BB_TRY(dev_alloc((char **)&s->d_part, (s->rowpart_elems + s->colpart_elems) * es));
+    BB_TRY(dev_alloc(&s->d_udesc, (int64_t)s->udesc.size()));
+    BB_TRY(dev_alloc(&s->d_wave_begin, nw + 1));
+    BB_TRY(dev_alloc(&s->d_wave_slot, nw));
+    BB_TRY(dev_alloc(&s->d_stresspart, nw));
+    BB_TRY(dev_alloc(&s->d_blk_ptr, nb + 1));
+    BB_TRY(dev_alloc(&s->d_blk_chunk, (int64_t)blk_chunk.size()));
+    BB_TRY(dev_alloc(&s->d_stress_hist, kHistCap));
+    BB_TRY(dev_alloc(&s->d_stress_scalar, 1));
+    BB_TRY(dev_alloc(&s->d_f64_tmp, s->L.n_pad * 3));
+    BB_TRY(dev_alloc((char **)&s->d_exch, (3 * s->L.n_pad + 2) * es));
+    s->own_exch = true;
+    s->hist_cap = kHistCap;
+
+    hipStream_t st = s->stream;
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_udesc, s->udesc.data(), s->udesc.size() * sizeof(int2),
+                                hipMemcpyHostToDevice, st));
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_wave_begin, wave_begin.data(), (nw + 1) * sizeof(int64_t),
+                                hipMemcpyHostToDevice, st));
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_wave_slot, wave_slot.data(), nw * sizeof(int32_t),
+                                hipMemcpyHostToDevice, st));
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_blk_ptr, blk_ptr.data(), (nb + 1) * sizeof(int64_t),
+                                hipMemcpyHostToDevice, st));
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_blk_chunk, blk_chunk.data(),
+                                blk_chunk.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    // rows of boundary tiles owned by another rank are never written: keep them 0
+    BB_HIP_CHECK(hipMemsetAsync(s->d_part, 0, (size_t)(s->rowpart_elems + s->colpart_elems) * es, st));
+    BB_HIP_CHECK(hipMemsetAsync(s->d_X, 0, (size_t)(s->L.n_pad * 3 * es), st));
+    BB_HIP_CHECK(hipMemsetAsync(s->d_exch, 0, (size_t)((3 * s->L.n_pad + 2) * es), st));
+    BB_HIP_CHECK(hipMemsetAsync(s->d_stresspart, 0, (size_t)nw * sizeof(double), st));
+    BB_HIP_CHECK(hipStreamSynchronize(st));  // the host vectors above die with this scope
+    return BB_OK;
+}
+
+template <typename T>
+int launch_grad_t(bb_solver *s) {
+    GradParams<T> p;
+    p.units = (const T *)s->d_units;
+    p.X = (const T *)s->d_X;
+    p.udesc = s->d_udesc;
+    p.wave_begin = s->d_wave_begin;
+    p.wave_slot = s->d_wave_slot;
+    p.rowpart = (T *)s->d_part;
+    p.colpart = (T *)s->d_part + s->rowpart_elems;
+    p.stresspart = s->d_stresspart;
+    p.row_shift = s->u_begin - s->t_first * s->L.units_per_tile;
+    hipLaunchKernelGGL(stress_grad_kernel<T>, dim3(s->n_waves / 4), dim3(256), 0, s->stream, p);
+    BB_HIP_CHECK(hipGetLastError());
+    return BB_OK;
+}
+
+template <typename T>
+int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out) {
+    ReduceParams<T> p;
+    p.part = (const T *)s->d_part;
+    p.blk_ptr = s->d_blk_ptr;
+    p.blk_chunk = s->d_blk_chunk;
+    p.stresspart = s->d_stresspart;
+    p.X = (T *)s->d_X;
+    p.exch = (T *)s->d_exch;
+    p.stress_out = stress_out;
+    p.n_pad = s->L.n_pad;
+    p.n_waves = s->n_waves;
+    p.mode = mode;
+    p.lr = (T)lr;
+    const int grid = mode == kReduceStressOnly ? 1 : (int)s->L.n_blocks;
+    hipLaunchKernelGGL(reduce_kernel<T>, dim3(grid), dim3(256), 0, s->stream, p);
+    BB_HIP_CHECK(hipGetLastError());
+    return BB_OK;
+}
+
+int launch_grad(bb_solver *s) {
+    return s->dtype == BB_F32 ? launch_grad_t<float>(s) : launch_grad_t<double>(s);
+}
+int launch_reduce(bb_solver *s, int mode, double lr, double *stress_out) {
+    return s->dtype == BB_F32 ? launch_reduce_t<float>(s, mode, lr, stress_out)
+                              : launch_reduce_t<double>(s, mode, lr, stress_out);
+}
+
+hipEvent_t *timing_slot(bb_solver *s) {
+    if (!s->timing || s->ev_used + 3 > s->ev.size()) return nullptr;
+    hipEvent_t *e = &s->ev[s->ev_used];
+    s->ev_used += 3;
+    return e;
+}
+
+int check_ready(const bb_solver *s, const char *who) {
+    if (!s) return bb::fail(BB_ERR_INVALID, std::string(who) + ": solver is NULL");
+    if (!s->have_wish)
+        return bb::fail(BB_ERR_STATE, std::string(who) + ": no wish distances set");
+    if (!s->have_coords)
+        return bb::fail(BB_ERR_STATE, std::string(who) + ": no coordinates set");
+    return BB_OK;
+}
+
+template <typename T>
+int set_wish_dense_t(bb_solver *s, const double *host, int64_t ld, int kind, double alpha) {
+    constexpr int VW = Traits<T>::VW;
+    const int64_t upt = s->L.units_per_tile, n = s->L.n_bins;
+    constexpr int64_t kRunTiles = 8;  // tiles staged per copy
+    double *stage = nullptr;
+    BB_TRY(dev_alloc(&stage, kRunTiles * VW * VW));
+    // Copy, convert and the next copy are all enqueued on the solver's stream,
+    // so one staging buffer is enough and nothing depends on null-stream rules.
+    int rc = BB_OK;
+    int64_t ul = 0;
+    while (ul < s->n_local && rc == BB_OK) {
+        // a run: consecutive local units whose rows are consecutive in one strip
+        const int j0 = s->udesc[ul].y;
+        const int64_t i_start = s->udesc[ul].x;
+        int64_t ue = ul + 1;
+        while (ue < s->n_local && ue - ul < kRunTiles * upt && s->udesc[ue].y == j0 &&
+               s->udesc[ue].x == i_start + (ue - ul) * kRowsPerUnit)
+            ++ue;
+        const int64_t rows = (ue - ul) * kRowsPerUnit;
+        const int64_t rows_valid =
+            std::max<int64_t>(0, std::min<int64_t>(i_start + rows, n) - i_start);
+        const int64_t cols_valid =
+            std::max<int64_t>(0, std::min<int64_t>((int64_t)j0 + VW, n) - j0);
+        hipError_t e = hipSuccess;
+        if (rows_valid < rows || cols_valid < VW)
+            e = hipMemsetAsync(stage, 0, (size_t)rows * VW * sizeof(double), s->stream);
+        if (e == hipSuccess && rows_valid > 0 && cols_valid > 0)
+            e = hipMemcpy2DAsync(stage, VW * sizeof(double), host + i_start * ld + j0,
+                                 (size_t)ld * sizeof(double), (size_t)cols_valid * sizeof(double),
+                                 (size_t)rows_valid, hipMemcpyHostToDevice, s->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(convert_units_kernel<T>, dim3((unsigned)(ue - ul)), dim3(256), 0,
+                               s->stream, stage, (T *)s->d_units, s->d_udesc, ul, i_start, n,
+                               kind, -1.0 / alpha);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess)
+            rc = bb::fail(BB_ERR_HIP, std::string("set_wish_dense: ") + hipGetErrorString(e));
+        ul = ue;
+    }
+    hipError_t e = hipStreamSynchronize(s->stream);
+    if (rc == BB_OK && e != hipSuccess)
+        rc = bb::fail(BB_ERR_HIP, std::string("set_wish_dense: ") + hipGetErrorString(e));
+    hipFree(stage);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bb_solver_create(bb_solver **out, int64_t n_bins, int dtype, int device, int rank, int world,
+                     const int32_t *tile_I, const int32_t *tile_J, int64_t n_tiles) {
+    BB_REQUIRE(out != nullptr, "bb_solver_create: out is NULL");
+    *out = nullptr;
+    BB_REQUIRE(dtype == BB_F32 || dtype == BB_F64, "bb_solver_create: bad dtype");
+    BB_REQUIRE(n_bins >= 2, "bb_solver_create: n_bins must be >= 2");
+    BB_REQUIRE(n_bins <= (int64_t)700000000, "bb_solver_create: n_bins too large");
+    BB_REQUIRE(world >= 1 && rank >= 0 && rank < world, "bb_solver_create: bad rank/world");
+    BB_REQUIRE((tile_I == nullptr) == (tile_J == nullptr) && (tile_I != nullptr || n_tiles == 0),
+               "bb_solver_create: tile_I/tile_J/n_tiles inconsistent");
+    BB_TRY(bb::use_device(device));
+
+    bb_solver *s = new (std::nothrow) bb_solver();
+    if (!s) return bb::fail(BB_ERR_NOMEM, "bb_solver_create: out of host memory");
+    s->dtype = dtype;
+    s->device = device;
+    s->rank = rank;
+    s->world = world;
+    int rc = bb_layout_dense_info(n_bins, dtype, &s->L);
+    if (rc == BB_OK) {
+        if (tile_I == nullptr) {
+            s->tile_I.resize((size_t)s->L.n_tiles);
+            s->tile_J.resize((size_t)s->L.n_tiles);
+            rc = bb_layout_dense_tiles(n_bins, dtype, s->tile_I.data(), s->tile_J.data(),
+                                       s->L.n_tiles);
+        } else {
+            // blocked-sparse: validate order (J, then I ascending; I <= J < n_blocks)
+            for (int64_t t = 0; t < n_tiles && rc == BB_OK; ++t) {
+                const bool in_range = tile_I[t] >= 0 && tile_I[t] <= tile_J[t] &&
+                                      tile_J[t] < s->L.n_blocks;
+                const bool ordered =
+                    t == 0 || tile_J[t] > tile_J[t - 1] ||
+                    (tile_J[t] == tile_J[t - 1] && tile_I[t] > tile_I[t - 1]);
+                if (!in_range || !ordered)
+                    rc = bb::fail(BB_ERR_INVALID,
+                                  "bb_solver_create: tile list must be strictly ordered by "
+                                  "(J, I) with 0 <= I <= J < n_blocks");
+            }
+            s->tile_I.assign(tile_I, tile_I + n_tiles);
+            s->tile_J.assign(tile_J, tile_J + n_tiles);
+            s->L.n_tiles = n_tiles;
+            s->L.n_units = n_tiles * s->L.units_per_tile;
+        }
+    }
+    if (rc == BB_OK) rc = bb_layout_rank_units(s->L.n_units, rank, world, &s->u_begin, &s->u_end);
+    if (rc == BB_OK) {
+        hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+        if (e != hipSuccess)
+            rc = bb::fail(BB_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+        else
+            s->own_stream = true;
+    }
+    if (rc == BB_OK) rc = build_indices(s);
+    if (rc != BB_OK) {
+        std::string keep = bb_last_error();
+        bb_solver_destroy(s);
+        bb::set_error(keep);
+        return rc;
+    }
+    *out = s;
+    return BB_OK;
+}
+
+int bb_solver_destroy(bb_solver *s) {
+    if (!s) return BB_OK;
+    hipSetDevice(s->device);
+    if (s->stream || !s->own_stream) hipStreamSynchronize(s->stream);
+    for (hipEvent_t e : s->ev) hipEventDestroy(e);
+    hipFree(s->d_units);
+    hipFree(s->d_X);
+    hipFree(s->d_part);
+    if (s->own_exch) hipFree(s->d_exch);
+    hipFree(s->d_udesc);
+    hipFree(s->d_wave_begin);
+    hipFree(s->d_wave_slot);
+    hipFree(s->d_stresspart);
+    hipFree(s->d_blk_ptr);
+    hipFree(s->d_blk_chunk);
+    hipFree(s->d_stress_hist);
+    hipFree(s->d_stress_scalar);
+    hipFree(s->d_f64_tmp);
+    if (s->own_stream && s->stream) hipStreamDestroy(s->stream);
+    delete s;
+    return BB_OK;
+}
+
+int bb_solver_set_stream(bb_solver *s, void *hip_stream) {
+    BB_REQUIRE(s != nullptr, "bb_solver_set_stream: solver is NULL");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (s->own_stream && s->stream) hipStreamDestroy(s->stream);
+    s->stream = (hipStream_t)hip_stream;
+    s->own_stream = false;
+    return BB_OK;
+}
+
+int bb_solver_layout(const bb_solver *s, bb_layout_info *info, int64_t *u_begin, int64_t *u_end) {
+    BB_REQUIRE(s != nullptr, "bb_solver_layout: solver is NULL");
+    if (info) *info = s->L;
+    if (u_begin) *u_begin = s->u_begin;
+    if (u_end) *u_end = s->u_end;
+    return BB_OK;
+}
+
+int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld, int kind,
+                             double alpha) {
+    BB_REQUIRE(s != nullptr && host != nullptr, "bb_solver_set_wish_dense: NULL argument");
+    BB_REQUIRE(ld >= s->L.n_bins, "bb_solver_set_wish_dense: ld < n_bins");
+    BB_REQUIRE(kind == BB_KIND_WISH || kind == BB_KIND_COUNTS,
+               "bb_solver_set_wish_dense: bad kind");
+    BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_dense: alpha must be > 0");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    int rc = s->dtype == BB_F32 ? set_wish_dense_t<float>(s, host, ld, kind, alpha)
+                                : set_wish_dense_t<double>(s, host, ld, kind, alpha);
+    if (rc == BB_OK) s->have_wish = true;
+    return rc;
+}
+
+int bb_solver_set_wish_from_coords(bb_solver *s, const double *xstar) {
+    BB_REQUIRE(s != nullptr && xstar != nullptr, "bb_solver_set_wish_from_coords: NULL argument");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_HIP_CHECK(hipMemsetAsync(s->d_f64_tmp, 0, (size_t)s->L.n_pad * 3 * sizeof(double), s->stream));
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_f64_tmp, xstar, (size_t)s->L.n_bins * 3 * sizeof(double),
+                                hipMemcpyHostToDevice, s->stream));
+    if (s->n_local > 0) {
+        if (s->dtype == BB_F32)
+            hipLaunchKernelGGL(gen_units_kernel<float>, dim3((unsigned)s->n_local), dim3(256), 0,
+                               s->stream, s->d_f64_tmp, (float *)s->d_units, s->d_udesc,
+                               s->L.n_bins);
+        else
+            hipLaunchKernelGGL(gen_units_kernel<double>, dim3((unsigned)s->n_local), dim3(256), 0,
+                               s->stream, s->d_f64_tmp, (double *)s->d_units, s->d_udesc,
+                               s->L.n_bins);
+        BB_HIP_CHECK(hipGetLastError());
+    }
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    s->have_wish = true;
+    return BB_OK;
+}
+
+int bb_solver_set_coords(bb_solver *s, const double *xyz) {
+    BB_REQUIRE(s != nullptr && xyz != nullptr, "bb_solver_set_coords: NULL argument");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    const int64_t n3 = s->L.n_pad * 3;
+    BB_HIP_CHECK(hipMemsetAsync(s->d_f64_tmp, 0, (size_t)n3 * sizeof(double), s->stream));
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_f64_tmp, xyz, (size_t)s->L.n_bins * 3 * sizeof(double),
+                                hipMemcpyHostToDevice, s->stream));
+    const unsigned grid = (unsigned)((n3 + 255) / 256);
+    if (s->dtype == BB_F32)
+        hipLaunchKernelGGL(f64_to_T_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
+                           s->d_f64_tmp, (float *)s->d_X, n3);
+    else
+        hipLaunchKernelGGL(f64_to_T_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
+                           s->d_f64_tmp, (double *)s->d_X, n3);
+    BB_HIP_CHECK(hipGetLastError());
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    s->have_coords = true;
+    s->hist_n = 0;
+    s->grad_pending = false;
+    return BB_OK;
+}
+
+int bb_solver_get_coords(bb_solver *s, double *xyz) {
+    BB_REQUIRE(s != nullptr && xyz != nullptr, "bb_solver_get_coords: NULL argument");
+    if (!s->have_coords) return bb::fail(BB_ERR_STATE, "bb_solver_get_coords: no coordinates set");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    const int64_t n3 = s->L.n_pad * 3;
+    const unsigned grid = (unsigned)((n3 + 255) / 256);
+    if (s->dtype == BB_F32)
+        hipLaunchKernelGGL(T_to_f64_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
+                           (const float *)s->d_X, s->d_f64_tmp, n3);
+    else
+        hipLaunchKernelGGL(T_to_f64_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
+                           (const double *)s->d_X, s->d_f64_tmp, n3);
+    BB_HIP_CHECK(hipGetLastError());
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    BB_HIP_CHECK(hipMemcpy(xyz, s->d_f64_tmp, (size_t)s->L.n_bins * 3 * sizeof(double),
+                           hipMemcpyDeviceToHost));
+    return BB_OK;
+}
+
+int bb_solver_iterate(bb_solver *s, int64_t iters, double lr) {
+    BB_TRY(check_ready(s, "bb_solver_iterate"));
+    BB_REQUIRE(iters >= 0, "bb_solver_iterate: iters < 0");
+    if (s->world != 1)
+        return bb::fail(BB_ERR_STATE,
+                        "bb_solver_iterate: world > 1 needs bb_solver_grad / all-reduce / "
+                        "bb_solver_apply");
+    if (s->hist_n + iters > s->hist_cap)
+        return bb::fail(BB_ERR_STATE, "bb_solver_iterate: stress history full");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    for (int64_t k = 0; k < iters; ++k) {
+        hipEvent_t *ev = timing_slot(s);
+        if (ev) BB_HIP_CHECK(hipEventRecord(ev[0], s->stream));
+        BB_TRY(launch_grad(s));
+        if (ev) BB_HIP_CHECK(hipEventRecord(ev[1], s->stream));
+        BB_TRY(launch_reduce(s, kReduceApply, lr, s->d_stress_hist + s->hist_n));
+        if (ev) BB_HIP_CHECK(hipEventRecord(ev[2], s->stream));
+        s->hist_n++;
+    }
+    return BB_OK;
+}
+
+int bb_solver_grad(bb_solver *s) {
+    BB_TRY(check_ready(s, "bb_solver_grad"));
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    hipEvent_t *ev = timing_slot(s);
+    if (ev) BB_HIP_CHECK(hipEventRecord(ev[0], s->stream));
+    BB_TRY(launch_grad(s));
+    if (ev) BB_HIP_CHECK(hipEventRecord(ev[1], s->stream));
+    BB_TRY(launch_reduce(s, kReduceExchange, 0.0, nullptr));
+    if (ev) BB_HIP_CHECK(hipEventRecord(ev[2], s->stream));
+    s->grad_pending = true;
+    return BB_OK;
+}
+
+int bb_solver_apply(bb_solver *s, double lr) {
+    BB_TRY(check_ready(s, "bb_solver_apply"));
+    if (!s->grad_pending)
+        return bb::fail(BB_ERR_STATE, "bb_solver_apply: no bb_solver_grad pending");
+    if (s->hist_n + 1 > s->hist_cap)
+        return bb::fail(BB_ERR_STATE, "bb_solver_apply: stress history full");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    const int64_t n3 = s->L.n_pad * 3;
+    const unsigned grid = (unsigned)((n3 + 255) / 256);
+    if (s->dtype == BB_F32)
+        hipLaunchKernelGGL(apply_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
+                           (float *)s->d_X, (const float *)s->d_exch, n3, (float)lr,
+                           s->d_stress_hist + s->hist_n);
+    else
+        hipLaunchKernelGGL(apply_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
+                           (double *)s->d_X, (const double *)s->d_exch, n3, lr,
+                           s->d_stress_hist + s->hist_n);
+    BB_HIP_CHECK(hipGetLastError());
+    s->hist_n++;
+    s->grad_pending = false;
+    return BB_OK;
+}
+
+int bb_solver_exchange_size(const bb_solver *s, int64_t *n_elems) {
+    BB_REQUIRE(s != nullptr && n_elems != nullptr, "bb_solver_exchange_size: NULL argument");
+    *n_elems = 3 * s->L.n_pad + 2;
+    return BB_OK;
+}
+
+int bb_solver_get_exchange_buffer(bb_solver *s, void **dev_ptr) {
+    BB_REQUIRE(s != nullptr && dev_ptr != nullptr, "bb_solver_get_exchange_buffer: NULL argument");
+    *dev_ptr = s->d_exch;
+    return BB_OK;
+}
+
+int bb_solver_set_exchange_buffer(bb_solver *s, void *dev_ptr) {
+    BB_REQUIRE(s != nullptr && dev_ptr != nullptr, "bb_solver_set_exchange_buffer: NULL argument");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (s->own_exch) hipFree(s->d_exch);
+    s->d_exch = dev_ptr;
+    s->own_exch = false;
+    return BB_OK;
+}
+
+int bb_solver_stress(bb_solver *s, double *stress) {
+    BB_TRY(check_ready(s, "bb_solver_stress"));
+    BB_REQUIRE(stress != nullptr, "bb_solver_stress: stress is NULL");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(launch_grad(s));
+    BB_TRY(launch_reduce(s, kReduceStressOnly, 0.0, s->d_stress_scalar));
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    BB_HIP_CHECK(hipMemcpy(stress, s->d_stress_scalar, sizeof(double), hipMemcpyDeviceToHost));
+    return BB_OK;
+}
+
+int bb_solver_get_stress_history(bb_solver *s, double *out, int64_t cap, int64_t *n) {
+    BB_REQUIRE(s != nullptr && n != nullptr, "bb_solver_get_stress_history: NULL argument");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    *n = s->hist_n;
+    const int64_t m = std::min(cap, s->hist_n);
+    if (out && m > 0)
+        BB_HIP_CHECK(hipMemcpy(out, s->d_stress_hist, (size_t)m * sizeof(double),
+                               hipMemcpyDeviceToHost));
+    return BB_OK;
+}
+
+int bb_solver_sync(bb_solver *s) {
+    BB_REQUIRE(s != nullptr, "bb_solver_sync: solver is NULL");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    return BB_OK;
+}
+
+int bb_solver_set_timing(bb_solver *s, int enabled) {
+    BB_REQUIRE(s != nullptr, "bb_solver_set_timing: solver is NULL");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (enabled && s->ev.empty()) {
+        s->ev.resize(3 * kMaxTimedLaunches);
+        for (auto &e : s->ev) BB_HIP_CHECK(hipEventCreate(&e));
+    }
+    s->timing = enabled != 0;
+    s->ev_used = 0;
+    return BB_OK;
+}
+
+int bb_solver_get_timing(bb_solver *s, double *grad_ms_avg, double *reduce_ms_avg,
+                         int64_t *launches) {
+    BB_REQUIRE(s != nullptr, "bb_solver_get_timing: solver is NULL");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    double g = 0.0, r = 0.0;
+    const size_t n = s->ev_used / 3;
+    for (size_t k = 0; k < n; ++k) {
+        float a = 0.f, b = 0.f;
+        BB_HIP_CHECK(hipEventElapsedTime(&a, s->ev[3 * k], s->ev[3 * k + 1]));
+        BB_HIP_CHECK(hipEventElapsedTime(&b, s->ev[3 * k + 1], s->ev[3 * k + 2]));
+        g += a;
+        r += b;
+    }
+    if (grad_ms_avg) *grad_ms_avg = n ? g / n : 0.0;
+    if (reduce_ms_avg) *reduce_ms_avg = n ? r / n : 0.0;
+    if (launches) *launches = (int64_t)n;
+    return BB_OK;
+}
+
+int bb_solver_traffic(const bb_solver *s, int64_t *unit_bytes, int64_t *pairs_dense) {
+    BB_REQUIRE(s != nullptr, "bb_solver_traffic: solver is NULL");
+    if (unit_bytes) *unit_bytes = s->n_local * bb::kUnitBytes;
+    if (pairs_dense) *pairs_dense = s->L.n_bins * (s->L.n_bins - 1) / 2;
+    return BB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+"""ContactMap -- the solver's input datatype.
+
+Mirrors the public surface of the reference's Cython class
+(`blueberry/datatypes.pyx:31-272`): same constructor arguments, public
+attributes (pyx:78-86), in-place / return-None methods and the
+`(n_bins+1, n_bins+1)` float64 matrix.  The two Cython loops of the class --
+the sparse-triple scatter (pyx:110-116) and KR + observed/expected
+normalisation (pyx:166-169, nan_to_num :171) -- run on the GPU through
+libblueberry_hip.so and are bit-exact against golden vectors captured from
+the real reference (tests/golden/contactmap.npz).  Everything the reference
+does with numpy / scipy / pandas stays numpy / scipy / pandas here.
+
+Deviations from the reference, all deliberate:
+  * `from_arrays` works: the reference's calls the file-loading constructor
+    and has no `return` (pyx:264-272), so it needs the lab's NFS files and
+    yields None.  Here it builds the map from the arrays alone, and takes
+    optional KRnorm / KRexpected so that `normalize()` is usable.
+  * path templates use `resolution // 1000` (the Python 2 meaning of the
+    reference's `resolution/1000`, pyx:90-95).
+  * `filter` also updates `n_bins` (= rows kept) and `regions` (the reference
+    leaves them stale, pyx:140-141) and drops the KR vectors, so a later
+    `normalize()` raises instead of indexing out of bounds --
+    `keep_stale=True` restores the old behaviour.
+  * `normalize` raises ZeroDivisionError up front when a divisor would be 0
+    (the reference raises from inside the loop, after modifying part of the
+    matrix, because Cython checks float division; golden flag
+    `cm_zero_kr_raises_zerodivision`).
+"""
+import numpy
+
+from . import _lib
+
+RAO = "/net/noble/vol1/data/hic-datasets/"
+RAW_DIR = RAO + ("data/Rao-Cell2014/rawFromGEO/{0}/{2}kb_resolution_intrachromosomal/chr{1}/"
+                 "MAPQGE30/chr{1}_{2}kb.RAWobserved")
+KR_NORM = RAO + ("data/Rao-Cell2014/rawFromGEO/{0}/{2}kb_resolution_intrachromosomal/chr{1}/"
+                 "MAPQGE30/chr{1}_{2}kb.KRnorm")
+KR_EXP = RAO + ("data/Rao-Cell2014/rawFromGEO/{0}/{2}kb_resolution_intrachromosomal/chr{1}/"
+                "MAPQGE30/chr{1}_{2}kb.KRexpected")
+
+
+def scatter_triples(triples, resolution, n_bins, device=0):
+    """(n,3) [pos_i, pos_j, count] rows -> dense symmetric (n_bins+1)^2 matrix.
+
+    GPU form of the loop at `blueberry/datatypes.pyx:110-116`: bin =
+    int(pos / resolution), both [j,k] and [k,j] set, later rows win."""
+    t = numpy.nan_to_num(numpy.asarray(triples, dtype=numpy.float64))   # pyx:102
+    if t.ndim != 2 or t.shape[1] != 3:
+        raise ValueError("triples must have shape (n, 3)")
+    # the reference's pointer arithmetic reads the array column-major (pyx:111-113)
+    cols = numpy.ascontiguousarray(t.T)
+    d = int(n_bins) + 1
+    matrix = numpy.zeros((d, d), dtype=numpy.float64)                   # pyx:99
+    _lib.check(_lib.load().bb_contactmap_scatter(
+        _lib.as_f64_ptr(cols), t.shape[0], int(resolution), _lib.as_f64_ptr(matrix), d,
+        int(device)), "bb_contactmap_scatter")
+    return matrix
+
+
+class ContactMap(object):
+    """This is a contact map for Hi-C datasets.
+
+    Same parameters and attributes as the reference class
+    (`blueberry/datatypes.pyx:31-76`).
+
+    Parameters
+    ----------
+    celltype : str
+    chromosome : int
+    resolution : int
+
+    Attributes
+    ----------
+    resolution, chromosome, celltype, filename, n_bins
+    matrix : numpy.ndarray, shape=(n_bins+1, n_bins+1), float64
+    regions : numpy.ndarray -- the midpoints found in this map
+    """
+
+    def __init__(self, celltype, chromosome, resolution=1000, device=0):
+        import pandas
+        self.resolution = int(resolution)
+        self.chromosome = chromosome
+        self.celltype = celltype
+        self.device = int(device)
+        kb = self.resolution // 1000
+        self.filename = RAW_DIR.format(celltype, chromosome, kb)
+        self._KRnorm = numpy.atleast_1d(numpy.loadtxt(KR_NORM.format(celltype, chromosome, kb)))
+        self._KRexpected = numpy.atleast_1d(numpy.loadtxt(KR_EXP.format(celltype, chromosome, kb)))
+        self.n_bins = int(self._KRnorm.shape[0])
+        data = pandas.read_csv(self.filename, delimiter="\t", engine="c", dtype="float64",
+                               header=None).values
+        data = numpy.nan_to_num(data)
+        self.matrix = scatter_triples(data, self.resolution, self.n_bins, self.device)
+        self.regions = numpy.union1d(data[:, 0], data[:, 1])
+        self.regions.sort()
+
+    # ------------------------------------------------------------------
+    @classmethod
+    def from_arrays(cls, celltype, chromosome, resolution, contacts, n_bins=None, KRnorm=None,
+                    KRexpected=None, symmetric=True, device=0):
+        """Create a contact map from numpy arrays.  No files required.
+
+        contacts : (n, 3) array of (mid1, mid2, statistic), mid = bin midpoint,
+        placed at bin int((mid - resolution/2) / resolution) as at
+        `blueberry/datatypes.pyx:268-271`.  `symmetric` also sets the mirrored
+        cell (the file constructor's matrices are symmetric; the reference's
+        from_arrays would have set one triangle only)."""
+        self = cls.__new__(cls)
+        self.resolution = int(resolution)
+        self.chromosome = chromosome
+        self.celltype = celltype
+        self.device = int(device)
+        self.filename = ""
+        contacts = numpy.asarray(contacts, dtype=numpy.float64)
+        if contacts.ndim != 2 or contacts.shape[1] != 3:
+            raise ValueError("contacts must have shape (n, 3)")
+        b1 = ((contacts[:, 0] - self.resolution / 2.0) / self.resolution).astype(numpy.int64)
+        b2 = ((contacts[:, 1] - self.resolution / 2.0) / self.resolution).astype(numpy.int64)
+        if n_bins is None:
+            n_bins = (KRnorm.shape[0] if KRnorm is not None
+                      else int(max(b1.max(initial=-1), b2.max(initial=-1)) + 1))
+        self.n_bins = int(n_bins)
+        if contacts.shape[0] and (min(b1.min(), b2.min()) < 0 or
+                                  max(b1.max(), b2.max()) > self.n_bins):
+            raise ValueError("a contact falls outside [0, n_bins]")
+        d = self.n_bins + 1
+        self.matrix = numpy.zeros((d, d), dtype=numpy.float64)
+        for k in range(contacts.shape[0]):          # later rows win, as in the reference
+            self.matrix[b1[k], b2[k]] = contacts[k, 2]
+            if symmetric:
+                self.matrix[b2[k], b1[k]] = contacts[k, 2]
+        self.regions = numpy.union1d(contacts[:, 0], contacts[:, 1])
+        self._KRnorm = None if KRnorm is None else numpy.asarray(KRnorm, dtype=numpy.float64)
+        self._KRexpected = (None if KRexpected is None
+                            else numpy.asarray(KRexpected, dtype=numpy.float64))
+        return self
+
+    @classmethod
+    def from_matrix(cls, matrix, resolution=1000, celltype="", chromosome=0, KRnorm=None,
+                    KRexpected=None, device=0):
+        """Wrap an existing dense symmetric ((n_bins+1)^2) float64 matrix."""
+        self = cls.__new__(cls)
+        m = numpy.ascontiguousarray(matrix, dtype=numpy.float64)
+        if m.ndim != 2 or m.shape[0] != m.shape[1] or m.shape[0] < 1:
+            raise ValueError("matrix must be square")
+        self.resolution, self.chromosome, self.celltype = int(resolution), chromosome, celltype
+        self.device, self.filename = int(device), ""
+        self.matrix = m
+        self.n_bins = m.shape[0] - 1
+        self.regions = numpy.arange(self.n_bins, dtype=numpy.float64) * self.resolution
+        self._KRnorm = None if KRnorm is None else numpy.asarray(KRnorm, dtype=numpy.float64)
+        self._KRexpected = (None if KRexpected is None
+                            else numpy.asarray(KRexpected, dtype=numpy.float64))
+        return self
+
+    # ------------------------------------------------------------------
+    def filter(self, threshold=0, keep_stale=False):
+        """Remove rows and columns whose marginal count is <= threshold.
+
+        In place, returns None (`blueberry/datatypes.pyx:122-141`)."""
+        marginals = self.matrix.sum(axis=0)
+        keep = marginals > threshold
+        self.matrix = numpy.ascontiguousarray(self.matrix[keep][:, keep])
+        if not keep_stale:
+            # bins that survive, in the old numbering; the zero padding row
+            # (index n_bins) never survives threshold >= 0
+            self.n_bins = int(self.matrix.shape[0])
+            if self.regions is not None and self.regions.shape[0]:
+                bins = (self.regions / self.resolution).astype(numpy.int64)
+                ok = (bins >= 0) & (bins < keep.shape[0])
+                ok[ok] = keep[bins[ok]]
+                self.regions = self.regions[ok]
+            # KR vectors describe the unfiltered map: normalize() first, then filter()
+            self._KRnorm = None
+            self._KRexpected = None
+
+    def normalize(self):
+        """KR matrix balancing and observed/expected normalisation, in place.
+
+        m[j, j+i] /= KRnorm[j] * KRnorm[j+i] * KRexpected[i], mirrored, then
+        nan_to_num (`blueberry/datatypes.pyx:143-171`); runs on the GPU."""
+        if self._KRnorm is None or self._KRexpected is None:
+            raise ValueError("normalize() needs KRnorm and KRexpected")
+        n = self.n_bins
+        if self.matrix.shape != (n + 1, n + 1):
+            raise ValueError("matrix shape does not match n_bins (was filter() used with "
+                             "keep_stale=True?)")
+        if self._KRnorm.shape[0] < n or self._KRexpected.shape[0] < n:
+            raise ValueError("KRnorm / KRexpected shorter than n_bins")
+        kr = numpy.ascontiguousarray(self._KRnorm[:n], dtype=numpy.float64)
+        ke = numpy.ascontiguousarray(self._KRexpected[:n], dtype=numpy.float64)
+        if n and (numpy.any(kr == 0.0) or numpy.any(ke == 0.0)):
+            raise ZeroDivisionError("float division")
+        m = numpy.ascontiguousarray(self.matrix, dtype=numpy.float64)
+        _lib.check(_lib.load().bb_contactmap_normalize(
+            _lib.as_f64_ptr(m), n, _lib.as_f64_ptr(kr), _lib.as_f64_ptr(ke), self.device),
+            "bb_contactmap_normalize")
+        self.matrix = m
+
+    def correlation(self):
+        """Convert the map to a correlation map, in place (pyx:173-188)."""
+        self.matrix = numpy.corrcoef(self.matrix)
+
+    def plot(self, arcsinh=True, **kwargs):
+        """Plot the contact map onto the current palette (pyx:190-214)."""
+        import matplotlib.pyplot as plt
+        plt.title("{} chr{} at {}kb resolution".format(self.celltype, self.chromosome,
+                                                       self.resolution // 1000), fontsize=16)
+        plt.xlabel("Genomic Coordinate (kb)", fontsize=14)
+        plt.ylabel("Genomic Coordinate (kb)", fontsize=14)
+        plt.xticks(fontsize=14)
+        plt.yticks(fontsize=14)
+        plt.imshow(numpy.arcsinh(self.matrix) if arcsinh else self.matrix, **kwargs)
+
+    def eigenvector(self):
+        """First eigenvector of the matrix (restarted Lanczos, pyx:216-235)."""
+        import scipy.sparse.linalg
+        _, eigenvectors = scipy.sparse.linalg.eigsh(self.matrix, k=1)
+        return eigenvectors[:, 0]

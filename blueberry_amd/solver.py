@@ -1,0 +1,315 @@
+"""StructureSolver -- contact matrix -> 3D coordinates on MI355X.
+
+Host side of the hot path BASELINE.json names.  The reference has no solver
+(SURVEY.md section 0); the estimator shape follows the only estimator the
+reference has, `FitHiC(hyper-parameters).fit_transform(data)`
+(`blueberry/fithic.py:76-108`), and the input is the dense float64 matrix a
+`ContactMap` holds (`blueberry/datatypes.pyx:78-86`).  The algorithm is
+specified in docs/SPEC.md and runs entirely in libblueberry_hip.so
+(include/blueberry_hip.h); this module only validates arguments, owns the
+handle and, for world_size > 1, drives one all-reduce per iteration through
+torch.distributed (backend "nccl" = RCCL over xGMI).
+"""
+import os
+
+import numpy
+
+from . import _lib
+
+_DTYPES = {"float32": _lib.BB_F32, "float64": _lib.BB_F64}
+_KINDS = {"wish": _lib.BB_KIND_WISH, "counts": _lib.BB_KIND_COUNTS}
+
+
+class HipEngine(object):
+    """One rank's device state: thin, 1:1 over the bb_solver_* C-ABI."""
+
+    def __init__(self, n_bins, dtype, rank=0, world=1, device=0, tiles=None):
+        self._lib = _lib.load()
+        self._h = _lib.c_void_p()
+        self.n_bins, self.dtype, self.rank, self.world, self.device = (
+            int(n_bins), dtype, int(rank), int(world), int(device))
+        if tiles is None:
+            ti = tj = None
+            nt = 0
+        else:
+            ti = numpy.ascontiguousarray(tiles[0], dtype=numpy.int32)
+            tj = numpy.ascontiguousarray(tiles[1], dtype=numpy.int32)
+            if ti.shape != tj.shape or ti.ndim != 1:
+                raise ValueError("tiles must be a pair of equal-length 1-D index arrays")
+            nt = ti.shape[0]
+        _lib.check(self._lib.bb_solver_create(
+            self._h, self.n_bins, _DTYPES[dtype], self.device, self.rank, self.world,
+            None if ti is None else ti.ctypes.data_as(_lib.p_i32),
+            None if tj is None else tj.ctypes.data_as(_lib.p_i32), nt), "bb_solver_create")
+        self._exch = None
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if self._h:
+            self._lib.bb_solver_destroy(self._h)
+            self._h = _lib.c_void_p()
+            self._exch = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- layout -----------------------------------------------------------
+    def layout(self):
+        info = _lib.LayoutInfo()
+        ub, ue = _lib.c_i64(), _lib.c_i64()
+        _lib.check(self._lib.bb_solver_layout(self._h, info, ub, ue), "bb_solver_layout")
+        d = info.as_dict()
+        d["u_begin"], d["u_end"] = int(ub.value), int(ue.value)
+        return d
+
+    # -- inputs -----------------------------------------------------------
+    def set_wish_dense(self, matrix, kind, alpha):
+        m = _check_square(matrix, self.n_bins)
+        _lib.check(self._lib.bb_solver_set_wish_dense(
+            self._h, _lib.as_f64_ptr(m), m.strides[0] // 8, _KINDS[kind], float(alpha)),
+            "bb_solver_set_wish_dense")
+
+    def set_wish_from_coords(self, xstar):
+        x = _check_coords(xstar, self.n_bins)
+        _lib.check(self._lib.bb_solver_set_wish_from_coords(self._h, _lib.as_f64_ptr(x)),
+                   "bb_solver_set_wish_from_coords")
+
+    def set_coords(self, x0):
+        x = _check_coords(x0, self.n_bins)
+        _lib.check(self._lib.bb_solver_set_coords(self._h, _lib.as_f64_ptr(x)),
+                   "bb_solver_set_coords")
+
+    def get_coords(self):
+        out = numpy.empty((self.n_bins, 3), dtype=numpy.float64)
+        _lib.check(self._lib.bb_solver_get_coords(self._h, _lib.as_f64_ptr(out)),
+                   "bb_solver_get_coords")
+        return out
+
+    # -- iterations -------------------------------------------------------
+    def iterate(self, iters, lr):
+        _lib.check(self._lib.bb_solver_iterate(self._h, int(iters), float(lr)),
+                   "bb_solver_iterate")
+
+    def grad(self):
+        _lib.check(self._lib.bb_solver_grad(self._h), "bb_solver_grad")
+
+    def apply(self, lr):
+        _lib.check(self._lib.bb_solver_apply(self._h, float(lr)), "bb_solver_apply")
+
+    def stress(self):
+        out = _lib.c_dbl()
+        _lib.check(self._lib.bb_solver_stress(self._h, out), "bb_solver_stress")
+        return float(out.value)
+
+    def stress_history(self):
+        n = _lib.c_i64()
+        _lib.check(self._lib.bb_solver_get_stress_history(self._h, None, 0, n),
+                   "bb_solver_get_stress_history")
+        out = numpy.empty(int(n.value), dtype=numpy.float64)
+        if out.size:
+            _lib.check(self._lib.bb_solver_get_stress_history(
+                self._h, _lib.as_f64_ptr(out), out.size, n), "bb_solver_get_stress_history")
+        return out
+
+    def sync(self):
+        _lib.check(self._lib.bb_solver_sync(self._h), "bb_solver_sync")
+
+    # -- the all-reduce boundary (world > 1) --------------------------------
+    def exchange_tensor(self):
+        """A torch tensor aliasing the exchange buffer [g (n_pad,3) | hi | lo].
+
+        torch allocates it (plumbing: it is what torch.distributed can reduce)
+        and the solver is told to write its partial gradient there; the solver
+        is also moved onto torch's current stream so that the collective and
+        the kernels are ordered without host synchronisation."""
+        if self._exch is None:
+            import torch
+            n = _lib.c_i64()
+            _lib.check(self._lib.bb_solver_exchange_size(self._h, n), "bb_solver_exchange_size")
+            tdt = torch.float32 if self.dtype == "float32" else torch.float64
+            dev = torch.device("cuda", self.device)
+            self._exch = torch.zeros(int(n.value), dtype=tdt, device=dev)
+            stream = torch.cuda.current_stream(dev)
+            _lib.check(self._lib.bb_solver_set_stream(self._h, _lib.c_void_p(stream.cuda_stream)),
+                       "bb_solver_set_stream")
+            _lib.check(self._lib.bb_solver_set_exchange_buffer(
+                self._h, _lib.c_void_p(self._exch.data_ptr())), "bb_solver_set_exchange_buffer")
+        return self._exch
+
+    # -- measurement ------------------------------------------------------
+    def set_timing(self, enabled):
+        _lib.check(self._lib.bb_solver_set_timing(self._h, 1 if enabled else 0),
+                   "bb_solver_set_timing")
+
+    def timing(self):
+        g, r, n = _lib.c_dbl(), _lib.c_dbl(), _lib.c_i64()
+        _lib.check(self._lib.bb_solver_get_timing(self._h, g, r, n), "bb_solver_get_timing")
+        return {"grad_ms": float(g.value), "reduce_ms": float(r.value), "launches": int(n.value)}
+
+    def traffic(self):
+        b, p = _lib.c_i64(), _lib.c_i64()
+        _lib.check(self._lib.bb_solver_traffic(self._h, b, p), "bb_solver_traffic")
+        return {"unit_bytes": int(b.value), "pairs_dense": int(p.value)}
+
+
+def _check_square(matrix, n_bins):
+    m = numpy.asarray(matrix)
+    if m.ndim != 2 or m.shape[0] != m.shape[1]:
+        raise ValueError("contact matrix must be square, got shape %r" % (m.shape,))
+    if m.shape[0] != n_bins:
+        raise ValueError("contact matrix has %d bins, solver was created for %d"
+                         % (m.shape[0], n_bins))
+    if m.dtype != numpy.float64 or m.strides[1] != 8 or m.strides[0] % 8 or m.strides[0] < 8 * n_bins:
+        m = numpy.ascontiguousarray(m, dtype=numpy.float64)
+    return m
+
+
+def _check_coords(x, n_bins):
+    x = numpy.ascontiguousarray(x, dtype=numpy.float64)
+    if x.shape != (n_bins, 3):
+        raise ValueError("coordinates must have shape (%d, 3), got %r" % (n_bins, x.shape))
+    if not numpy.all(numpy.isfinite(x)):
+        raise ValueError("coordinates must be finite")
+    return x
+
+
+def allreduce_exchange(t):
+    """Sum the exchange buffer over all ranks, in place.
+
+    backend nccl (= RCCL): one in-place all-reduce of 3*n_pad+2 elements on the
+    device, over xGMI.  backend gloo (CPU rehearsals and tests): staged through
+    host memory -- transport only, the arithmetic on either side is unchanged."""
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl" or not t.is_cuda:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    else:
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        t.copy_(host)
+
+
+def _dist_state(distributed):
+    """(rank, world) of the running torch.distributed job, or (0, 1)."""
+    if distributed is False:
+        return 0, 1
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        if distributed:
+            raise
+        return 0, 1
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    if distributed:
+        raise RuntimeError("distributed=True but torch.distributed is not initialised")
+    return 0, 1
+
+
+class StructureSolver(object):
+    """Infer 3D bin coordinates from a Hi-C contact matrix (metric MDS).
+
+    Minimises  S(X) = sum_{i<j, c_ij>0} (|x_i - x_j| - delta_ij)^2  with
+    delta_ij = c_ij^(-1/alpha), by `n_iter` gradient steps  X <- X - lr * grad S
+    (docs/SPEC.md).  With lr = 1/(2 N) and a complete matrix each step equals a
+    SMACOF / Guttman-transform step, so the stress never increases.
+
+    Parameters
+    ----------
+    n_iter : int
+        Number of iterations (fixed; there is no convergence test on the device).
+    lr : float or 'auto'
+        Step size; 'auto' = 1 / (2 * n_bins).
+    dtype : 'float32' or 'float64'
+        Arithmetic type on the GPU.
+    alpha : float
+        Count-to-distance exponent, delta = c^(-1/alpha).
+    kind : 'counts' or 'wish'
+        Whether the input matrix holds contact counts or wish distances.
+    seed : int
+        Seed of the default initial coordinates (numpy default_rng standard normal).
+    device : int or None
+        HIP device index; None = LOCAL_RANK (distributed) or 0.
+    distributed : bool or None
+        None: shard over the ranks of an initialised torch.distributed job if
+        there is one.  Every rank passes the same matrix and gets the same result.
+
+    Attributes
+    ----------
+    structure_ : numpy.ndarray, shape (n_bins, 3), float64
+    stress_ : numpy.ndarray, shape (n_iter,) -- stress BEFORE each step
+    n_bins_, lr_ : the problem size and the step actually used
+    """
+
+    def __init__(self, n_iter=100, lr="auto", dtype="float32", alpha=3.0, kind="counts",
+                 seed=0, device=None, distributed=None, engine=None):
+        if dtype not in _DTYPES:
+            raise ValueError("dtype must be 'float32' or 'float64'")
+        if kind not in _KINDS:
+            raise ValueError("kind must be 'counts' or 'wish'")
+        if int(n_iter) < 0:
+            raise ValueError("n_iter must be >= 0")
+        if not (lr == "auto" or float(lr) > 0):
+            raise ValueError("lr must be positive or 'auto'")
+        if not float(alpha) > 0:
+            raise ValueError("alpha must be positive")
+        self.n_iter, self.lr, self.dtype, self.alpha, self.kind, self.seed = (
+            int(n_iter), lr, dtype, float(alpha), kind, int(seed))
+        self.device, self.distributed = device, distributed
+        # Engine factory: the HIP engine unless a test injects another one to
+        # rehearse the multi-rank orchestration without a GPU.
+        self._engine_factory = engine if engine is not None else HipEngine
+
+    def _pick_device(self, world):
+        if self.device is not None:
+            return int(self.device)
+        return int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+
+    def fit(self, X, init=None):
+        """Solve for the structure of `X` (a ContactMap or a square ndarray)."""
+        matrix = getattr(X, "matrix", X)
+        matrix = numpy.asarray(matrix)
+        if matrix.ndim != 2 or matrix.shape[0] != matrix.shape[1]:
+            raise ValueError("contact matrix must be square, got shape %r" % (matrix.shape,))
+        n = matrix.shape[0]
+        if n < 2:
+            raise ValueError("need at least 2 bins")
+        rank, world = _dist_state(self.distributed)
+        lr = 1.0 / (2.0 * n) if self.lr == "auto" else float(self.lr)
+        if init is None:
+            init = numpy.random.default_rng(self.seed).standard_normal((n, 3))
+
+        eng = self._engine_factory(n, self.dtype, rank=rank, world=world,
+                                   device=self._pick_device(world))
+        try:
+            eng.set_wish_dense(matrix, self.kind, self.alpha)
+            eng.set_coords(init)
+            run_iterations(eng, self.n_iter, lr, world)
+            self.structure_ = eng.get_coords()
+            self.stress_ = eng.stress_history()
+        finally:
+            eng.close()
+        self.n_bins_, self.lr_ = n, lr
+        return self
+
+    def fit_transform(self, X, init=None):
+        """`fit(X)` and return the (n_bins, 3) coordinates."""
+        return self.fit(X, init=init).structure_
+
+
+def run_iterations(eng, n_iter, lr, world):
+    """n_iter solver iterations on an engine whose inputs are set.
+
+    world == 1: the whole loop is enqueued by one C call.  world > 1: per
+    iteration, local partial gradient -> all-reduce(sum) -> identical update on
+    every rank, so the replicas of X stay bit-identical."""
+    if world == 1:
+        eng.iterate(n_iter, lr)
+        return
+    t = eng.exchange_tensor()
+    for _ in range(n_iter):
+        eng.grad()
+        allreduce_exchange(t)
+        eng.apply(lr)

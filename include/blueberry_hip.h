@@ -1,0 +1,192 @@
+/*
+ * blueberry_hip.h -- C-ABI of libblueberry_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for the contact-matrix -> 3D-coordinates hot path of
+ * jmschrei/blueberry.  Plain C: pointers, sizes, int status codes.  No torch,
+ * numpy or C++ types cross this line.  The Python host (blueberry_amd/) binds
+ * it with ctypes; INTEGRATION.md shows the binding a maintainer of the
+ * reference would add.
+ *
+ * The reference has NO FFI / plugin interface: its "interface"
+ * is Python names star-exported from blueberry/__init__.py:38-43 and Cython
+ * `cpdef` functions taking numpy arrays.  Every entry point below therefore
+ * cites the reference *function or loop* it replaces; entry points of the
+ * 3D-structure solver cite docs/SPEC.md instead, because the reference
+ * contains no solver.
+ *
+ * Conventions
+ *   - every function returns BB_OK (0) or a BB_ERR_* code; bb_last_error()
+ *     returns a thread-local message for the last failure on this thread;
+ *   - host pointers are borrowed for the duration of the call only; device
+ *     memory is owned by opaque handles with explicit create/destroy;
+ *   - one handle = one device = one host thread at a time; the library never
+ *     calls the oracle or any CPU fallback: without a usable GPU every compute
+ *     entry point fails with BB_ERR_HIP.
+ */
+#ifndef BLUEBERRY_HIP_H
+#define BLUEBERRY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BB_API __attribute__((visibility("default")))
+
+#define BB_VERSION 100 /* 0.1.0 */
+
+enum {
+    BB_OK = 0,
+    BB_ERR_INVALID = 1, /* bad argument (null pointer, negative size, ...)   */
+    BB_ERR_HIP = 2,     /* a HIP runtime call failed / no usable device      */
+    BB_ERR_STATE = 3,   /* call sequence error (e.g. iterate before set_wish) */
+    BB_ERR_NOMEM = 4    /* host or device allocation failed                  */
+};
+
+enum { BB_F32 = 0, BB_F64 = 1 };              /* arithmetic type of the solver */
+enum { BB_KIND_WISH = 0, BB_KIND_COUNTS = 1 }; /* meaning of a dense input      */
+
+BB_API int bb_version(void);
+BB_API const char *bb_last_error(void);
+/* Number of visible HIP devices; BB_ERR_HIP (count = 0) when there is none. */
+BB_API int bb_device_count(int *count);
+
+/* ---------------------------------------------------------------------- */
+/* K1  count_band_regions   (reference: blueberry/blueberry.pyx:77-91)      */
+/* ---------------------------------------------------------------------- */
+
+/* t = #{(i, j) : 0 <= j < i < n, low <= regions[i] - regions[j] <= high}.
+ * `regions` is a host vector of n float64 (what the reference reads through
+ * `<double*> regions_ndarray.data`, pyx:80); low/high are C ints as at pyx:82
+ * (LOW_FITHIC_CUTOFF / HIGH_FITHIC_CUTOFF, blueberry/utils.py:25-26).  The
+ * count is exact (fp64 subtract, integer sum). */
+BB_API int bb_band_count(const double *regions, int64_t n, int32_t low, int32_t high,
+                         int device, int64_t *count);
+
+/* The same sum restricted to rows i in [i_begin, i_end): one rank's share of
+ * a row-sharded count (the shares are summed with an integer all-reduce). */
+BB_API int bb_band_count_rows(const double *regions, int64_t n, int32_t low, int32_t high,
+                              int64_t i_begin, int64_t i_end, int device, int64_t *count);
+
+/* ---------------------------------------------------------------------- */
+/* Device layout of the wish-distance matrix (docs/SPEC.md 3).  Host-only   */
+/* arithmetic: callable without a GPU.                                      */
+/* ---------------------------------------------------------------------- */
+
+typedef struct bb_layout_info {
+    int64_t n_bins;         /* N                                              */
+    int64_t n_pad;          /* N rounded up to a multiple of vw               */
+    int64_t vw;             /* tile edge = columns per wave row: 1 KiB/sizeof */
+    int64_t rows_per_unit;  /* 8                                              */
+    int64_t units_per_tile; /* vw / 8                                         */
+    int64_t n_blocks;       /* n_pad / vw                                     */
+    int64_t n_tiles;        /* upper-triangular tiles incl. the diagonal      */
+    int64_t n_units;        /* n_tiles * units_per_tile                       */
+} bb_layout_info;
+
+BB_API int bb_layout_dense_info(int64_t n_bins, int dtype, bb_layout_info *info);
+/* Tile list of the dense upper triangle in device order (column-strip major:
+ * J ascending, then I ascending, I <= J).  cap >= info.n_tiles. */
+BB_API int bb_layout_dense_tiles(int64_t n_bins, int dtype, int32_t *tile_I, int32_t *tile_J,
+                                 int64_t cap);
+/* Contiguous share of n_units units owned by `rank` of `world`. */
+BB_API int bb_layout_rank_units(int64_t n_units, int rank, int world, int64_t *u_begin,
+                                int64_t *u_end);
+
+/* ---------------------------------------------------------------------- */
+/* S0  3D-structure solver  (docs/SPEC.md; absent from the reference)       */
+/* ---------------------------------------------------------------------- */
+
+typedef struct bb_solver bb_solver;
+
+/* Create a solver for n_bins bins on `device`, playing `rank` of `world`
+ * ranks (world = 1: the whole matrix).  tile_I/tile_J (n_tiles entries, device
+ * order, I <= J) select the tiles that exist -- pairs outside them carry no
+ * constraint (blocked-sparse input); pass NULL / 0 for the dense upper
+ * triangle.  The solver runs on its own HIP stream unless bb_solver_set_stream
+ * replaces it. */
+BB_API int bb_solver_create(bb_solver **out, int64_t n_bins, int dtype, int device, int rank,
+                            int world, const int32_t *tile_I, const int32_t *tile_J,
+                            int64_t n_tiles);
+BB_API int bb_solver_destroy(bb_solver *s);
+
+/* Run on the caller's stream (a hipStream_t; NULL = the device's null stream),
+ * e.g. torch's current stream so that an external all-reduce is ordered with
+ * the kernels. */
+BB_API int bb_solver_set_stream(bb_solver *s, void *hip_stream);
+BB_API int bb_solver_layout(const bb_solver *s, bb_layout_info *info, int64_t *u_begin,
+                            int64_t *u_end);
+
+/* Dense (n_bins, n_bins) float64 host matrix, leading dimension ld elements;
+ * only elements [i][j] with i < j are read.  kind = BB_KIND_WISH: entries are
+ * wish distances (<= 0 / non-finite = no constraint).  kind = BB_KIND_COUNTS:
+ * entries are contact counts, converted on the device with
+ * delta = c^(-1/alpha) (SPEC 2.1).  This is the matrix a ContactMap holds
+ * (reference: blueberry/datatypes.pyx:78-86 `matrix`, float64, C-contiguous).
+ * Each rank uploads only its own units. */
+BB_API int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld, int kind,
+                                    double alpha);
+/* Synthetic input generated on the device: delta_ij = |x*_i - x*_j| for the
+ * (n_bins,3) float64 host coordinates `xstar`, so that
+ * N = 50k needs no 20 GB host matrix. */
+BB_API int bb_solver_set_wish_from_coords(bb_solver *s, const double *xstar);
+
+BB_API int bb_solver_set_coords(bb_solver *s, const double *xyz); /* (n_bins,3) f64 host */
+BB_API int bb_solver_get_coords(bb_solver *s, double *xyz);
+
+/* world = 1: `iters` iterations of { stress + gradient, X <- X - lr * g },
+ * enqueued back to back; stress history is kept on the device. */
+BB_API int bb_solver_iterate(bb_solver *s, int64_t iters, double lr);
+
+/* world > 1 (also valid for world = 1): one iteration in two halves around
+ * the caller's all-reduce(sum) of the exchange buffer.
+ *   bb_solver_grad : this rank's partial gradient and stress -> exchange buffer
+ *   bb_solver_apply: X <- X - lr * exchange[0:3*n_pad]; records the stress    */
+BB_API int bb_solver_grad(bb_solver *s);
+BB_API int bb_solver_apply(bb_solver *s, double lr);
+/* The exchange buffer: 3*n_pad + 2 elements of the solver's dtype,
+ * [ g (n_pad,3) | stress hi | stress lo ].  By default owned by the solver;
+ * a caller that needs to hand it to a collective library may supply its own
+ * device allocation of that size. */
+BB_API int bb_solver_exchange_size(const bb_solver *s, int64_t *n_elems);
+BB_API int bb_solver_get_exchange_buffer(bb_solver *s, void **dev_ptr);
+BB_API int bb_solver_set_exchange_buffer(bb_solver *s, void *dev_ptr);
+
+/* Stress of the current coordinates (one gradient pass, no update). */
+BB_API int bb_solver_stress(bb_solver *s, double *stress);
+/* Copies the stress history (one value per completed iteration since the
+ * last bb_solver_set_coords) to the host; synchronises the stream. */
+BB_API int bb_solver_get_stress_history(bb_solver *s, double *out, int64_t cap, int64_t *n);
+BB_API int bb_solver_sync(bb_solver *s);
+
+/* HIP-event timing of the dominant kernel (stress+gradient) and of the
+ * reduce/update kernel on the solver's stream.  Averages are over the
+ * launches since timing was (re-)enabled. */
+BB_API int bb_solver_set_timing(bb_solver *s, int enabled);
+BB_API int bb_solver_get_timing(bb_solver *s, double *grad_ms_avg, double *reduce_ms_avg,
+                                int64_t *launches);
+/* Bytes of wish-distance data the stress+gradient kernel streams per launch on
+ * this rank (resident units * unit bytes), and pairs evaluated. */
+BB_API int bb_solver_traffic(const bb_solver *s, int64_t *unit_bytes, int64_t *pairs_dense);
+
+/* ---------------------------------------------------------------------- */
+/* A2/A3  ContactMap build + normalise on the device                        */
+/*        (reference: blueberry/datatypes.pyx:97-116 and :161-171)          */
+/* ---------------------------------------------------------------------- */
+
+/* matrix (d,d) float64 host, d = n_bins+1, zero-filled on entry.  `triples`
+ * is the (n,3) array exactly as the reference's pointer arithmetic reads it:
+ * column-major (pos_i[0..n), pos_j[0..n), count[0..n)).  bin = pos/resolution
+ * truncated; later triples overwrite earlier ones. */
+BB_API int bb_contactmap_scatter(const double *triples, int64_t n, int32_t resolution,
+                                 double *matrix, int64_t d, int device);
+/* In place on the host matrix: m[j][j+i] /= KRnorm[j]*KRnorm[j+i]*KRexp[i],
+ * mirrored, then numpy.nan_to_num over the whole matrix.  bit-exact fp64. */
+BB_API int bb_contactmap_normalize(double *matrix, int64_t n_bins, const double *KRnorm,
+                                   const double *KRexpected, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLUEBERRY_HIP_H */

@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Run once, in the build container (needs /root/reference, Cython, gcc):
+
+    python tests/golden/make_golden.py
+
+What it does: copies `blueberry.pyx` and `datatypes.pyx` from the read-only
+reference checkout into a throw-away temp directory (never into this repo),
+puts a two-constant stub `utils.py` beside them (the reference's own
+`utils.py` is Python 2 and does not import; the two values are those at
+reference `blueberry/utils.py:25-26`), compiles them with pyximport, calls the
+real Cython functions on seeded synthetic inputs and stores inputs + outputs
+as small .npz fixtures.  The fixtures are data only; the GPU box and the test
+suite never see the reference.
+
+Functions captured (reference file:line):
+  count_band_regions      blueberry/blueberry.pyx:77-91
+  benjamini_hochberg      blueberry/blueberry.pyx:40-75
+  downsample              blueberry/blueberry.pyx:93-104
+  ContactMap.__init__     blueberry/datatypes.pyx:88-120
+  ContactMap.normalize    blueberry/datatypes.pyx:143-171
+"""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy
+
+REF = "/root/reference/blueberry"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference(tmp):
+    import pyximport
+    for f in ("blueberry.pyx", "datatypes.pyx"):
+        shutil.copy(os.path.join(REF, f), tmp)
+    with open(os.path.join(tmp, "utils.py"), "w") as fh:
+        fh.write("HIGH_FITHIC_CUTOFF = 10000000\nLOW_FITHIC_CUTOFF = 25000\n"
+                 "Q_LOWER_BOUND = 0.01\n")
+    open(os.path.join(tmp, "__init__.py"), "w").close()
+    pkg = os.path.basename(tmp)
+    sys.path.insert(0, os.path.dirname(tmp))   # `from .utils import *` needs a package
+    sys.path.insert(0, tmp)                    # datatypes.pyx does `from blueberry import *`
+    pyximport.install(language_level=2, build_dir=os.path.join(tmp, "_bld"),
+                      setup_args={"include_dirs": numpy.get_include()})
+    bb = __import__(pkg + ".blueberry", fromlist=["x"])
+    sys.modules["blueberry"] = bb
+    dt = __import__(pkg + ".datatypes", fromlist=["x"])
+    return bb, dt
+
+
+def band_cases():
+    rng = numpy.random.default_rng(0)
+    cases = {}
+    for res, tag in ((50000, "50kb"), (10000, "10kb"), (5000, "5kb")):
+        for n in (1, 2, 1000, 4096):
+            cases["uniform_%s_n%d" % (tag, n)] = numpy.arange(n) * float(res) + res / 2.0
+    for n in (257, 1000, 5000):
+        gaps = rng.integers(1, 40, size=n) * 5000.0
+        gaps[rng.random(n) < 0.02] += 3.0e6         # centromere-like holes
+        cases["gappy_n%d" % n] = numpy.cumsum(gaps) + 2500.0
+    # both bounds are inclusive (pyx:88)
+    cases["edge_exact_low"] = numpy.array([0.0, 25000.0, 50000.0])
+    cases["edge_exact_high"] = numpy.array([0.0, 10000000.0, 10000001.0, 9999999.0])
+    cases["edge_just_outside"] = numpy.array([0.0, 24999.0, 10000001.0, 10024999.0])
+    # unsorted: only (i, j<i) with regions[i]-regions[j] in band count
+    cases["unsorted"] = rng.permutation(numpy.arange(300) * 40000.0)
+    cases["descending"] = numpy.arange(200)[::-1] * 50000.0
+    cases["fractional"] = numpy.sort(rng.random(500) * 3.0e7)
+    cases["empty"] = numpy.zeros(0)
+    return cases
+
+
+def make_band(bb):
+    out = {}
+    for name, r in band_cases().items():
+        r = numpy.ascontiguousarray(r, dtype=numpy.float64)
+        out["in_" + name] = r
+        out["out_" + name] = numpy.int64(bb.count_band_regions(r))
+    numpy.savez_compressed(os.path.join(OUT, "band_count.npz"), **out)
+    print("band_count:", {k[4:]: int(v) for k, v in out.items() if k.startswith("out_")})
+
+
+def make_bh_downsample(bb):
+    rng = numpy.random.default_rng(2)
+    out = {}
+    for k, (d, n) in enumerate(((4, 10), (100, 1000), (1000, 179900), (50, 50))):
+        p = numpy.sort(rng.random(d) ** 3)
+        out["bh_p_%d" % k] = p
+        out["bh_n_%d" % k] = numpy.int64(n)
+        out["bh_q_%d" % k] = bb.benjamini_hochberg(p, n)
+    for k, n5 in enumerate((2, 7, 20)):
+        yp1 = rng.random((n5 * 5, n5 * 5)).astype(numpy.float32)
+        yp5i = (rng.random((n5, n5)) * 0.9).astype(numpy.float32)
+        out["ds_yp1_%d" % k] = yp1
+        out["ds_yp5i_%d" % k] = yp5i.copy()
+        out["ds_out_%d" % k] = bb.downsample(yp1, numpy.zeros_like(yp5i), yp5i.copy())
+    numpy.savez_compressed(os.path.join(OUT, "bh_downsample.npz"), **out)
+    print("bh/downsample cases written")
+
+
+def make_contactmap(dt, tmp):
+    """Drive the real ContactMap ctor + normalize on synthetic Rao-format files."""
+    rng = numpy.random.default_rng(3)
+    data_dir = os.path.join(tmp, "data")
+    os.makedirs(data_dir)
+    dt.RAW_DIR = os.path.join(data_dir, "{0}_chr{1}_{2}kb.RAWobserved")
+    dt.KR_NORM = os.path.join(data_dir, "{0}_chr{1}_{2}kb.KRnorm")
+    dt.KR_EXP = os.path.join(data_dir, "{0}_chr{1}_{2}kb.KRexpected")
+    out = {}
+    for k, (n_bins, res) in enumerate(((6, 50000), (64, 10000), (300, 5000))):
+        # sparse upper-triangle triples (pos_i <= pos_j), some duplicates (last wins)
+        nnz = max(8, n_bins * 6)
+        bi = rng.integers(0, n_bins, size=nnz)
+        bj = numpy.minimum(n_bins - 1, bi + rng.geometric(0.15, size=nnz) - 1)
+        counts = rng.integers(1, 500, size=nnz).astype(numpy.float64)
+        triples = numpy.stack([bi * float(res), bj * float(res), counts], axis=1)
+        kr = 0.5 + rng.random(n_bins)
+        kr[rng.random(n_bins) < 0.08] = numpy.nan     # unmappable bins, as in Rao KRnorm files
+        krexp = 50.0 / (1.0 + numpy.arange(n_bins)) + 0.1
+        tag = (("cell%d" % k), k + 1, res / 1000)     # py3: resolution/1000 is a float
+        numpy.savetxt(dt.RAW_DIR.format(*tag), triples, delimiter="\t", fmt="%.1f")
+        numpy.savetxt(dt.KR_NORM.format(*tag), kr)
+        numpy.savetxt(dt.KR_EXP.format(*tag), krexp)
+        cm = dt.ContactMap("cell%d" % k, k + 1, res)
+        assert cm.n_bins == n_bins
+        out["cm%d_triples" % k] = triples
+        out["cm%d_resolution" % k] = numpy.int64(res)
+        out["cm%d_krnorm" % k] = numpy.loadtxt(dt.KR_NORM.format(*tag))
+        out["cm%d_krexp" % k] = numpy.loadtxt(dt.KR_EXP.format(*tag))
+        out["cm%d_matrix_raw" % k] = cm.matrix.copy()
+        out["cm%d_regions" % k] = cm.regions.copy()
+        with numpy.errstate(all="ignore"):
+            cm.normalize()
+        out["cm%d_matrix_norm" % k] = cm.matrix.copy()
+    # A zero KR entry: Cython's default cdivision=False turns the C division
+    # at datatypes.pyx:168 into a checked one, so the reference raises.
+    numpy.savetxt(dt.KR_NORM.format("cell0", 1, 50.0), numpy.array([1.0, 0.0, 1.0, 1.0, 1.0, 1.0]))
+    cm = dt.ContactMap("cell0", 1, 50000)
+    try:
+        cm.normalize()
+        raised = False
+    except ZeroDivisionError:
+        raised = True
+    out["cm_zero_kr_raises_zerodivision"] = numpy.bool_(raised)
+    numpy.savez_compressed(os.path.join(OUT, "contactmap.npz"), **out)
+    print("contactmap cases written")
+
+
+def main():
+    tmp = tempfile.mkdtemp(prefix="bbref_")
+    try:
+        bb, dt = import_reference(tmp)
+        make_band(bb)
+        make_bh_downsample(bb)
+        make_contactmap(dt, tmp)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+        shutil.rmtree(os.path.expanduser("~/.pyxbld"), ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+"""CPU: the oracle against the reference's golden vectors (captured from the
+real Cython functions by tests/golden/make_golden.py) and, for the solver --
+which the reference does not contain -- against closed forms."""
+import numpy
+import pytest
+
+from tests import _oracle
+
+
+# ---- K1 count_band_regions (blueberry.pyx:77-91): exact -------------------
+def band_cases():
+    z = _oracle.golden("band_count")
+    return sorted(k[3:] for k in z.files if k.startswith("in_"))
+
+
+@pytest.mark.parametrize("name", band_cases())
+def test_band_count_matches_reference(oracle, name):
+    z = _oracle.golden("band_count")
+    assert oracle.count_band_regions(z["in_" + name]) == int(z["out_" + name])
+
+
+def test_band_count_closed_form(oracle):
+    # uniform 50 kb grid: pairs at distance d*50kb, d = 1..200
+    r = numpy.arange(1000) * 50000.0 + 25000
+    assert oracle.count_band_regions(r) == sum(1000 - d for d in range(1, 201)) == 179900
+
+
+def test_band_count_rows_partition(oracle):
+    r = _oracle.golden("band_count")["in_gappy_n1000"]
+    full = oracle.count_band_regions(r)
+    cuts = [0, 1, 333, 334, 900, 1000]
+    assert sum(oracle.count_band_regions_rows(r, a, b) for a, b in zip(cuts, cuts[1:])) == full
+
+
+# ---- A2/A3 ContactMap scatter + normalize (datatypes.pyx:97-171): bit-exact --
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_contactmap_matches_reference(oracle, k):
+    z = _oracle.golden("contactmap")
+    n_bins = z["cm%d_krnorm" % k].shape[0]
+    raw = oracle.contactmap_scatter(z["cm%d_triples" % k], int(z["cm%d_resolution" % k]), n_bins)
+    assert raw.shape == z["cm%d_matrix_raw" % k].shape
+    assert numpy.array_equal(raw, z["cm%d_matrix_raw" % k])
+    norm = oracle.contactmap_normalize(raw, z["cm%d_krnorm" % k], z["cm%d_krexp" % k])
+    assert numpy.array_equal(norm, z["cm%d_matrix_norm" % k])       # bit for bit
+    assert numpy.array_equal(norm, norm.T)
+
+
+def test_reference_raises_on_zero_kr():
+    assert bool(_oracle.golden("contactmap")["cm_zero_kr_raises_zerodivision"])
+
+
+# ---- f4: benjamini_hochberg / downsample (blueberry.pyx:40-75, 93-104) -----
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_bh_matches_reference(oracle, k):
+    z = _oracle.golden("bh_downsample")
+    q = oracle.benjamini_hochberg(z["bh_p_%d" % k], int(z["bh_n_%d" % k]))
+    assert numpy.array_equal(q, z["bh_q_%d" % k])
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_downsample_matches_reference(oracle, k):
+    z = _oracle.golden("bh_downsample")
+    out = oracle.downsample(z["ds_yp1_%d" % k], z["ds_yp5i_%d" % k])
+    assert numpy.array_equal(out, z["ds_out_%d" % k])
+
+
+# ---- S0 solver: PARITY UNPINNED vs the reference (it has no solver); --------
+# ---- pinned by closed forms instead (docs/SPEC.md) --------------------------
+def test_stress_zero_at_generating_coordinates(oracle):
+    x = _oracle.random_walk(60)
+    s, g = oracle.stress_grad(_oracle.wish_from_coords(x), x)
+    assert s < 1e-24 and numpy.abs(g).max() < 1e-11
+
+
+def test_tetrahedron_closed_form(oracle):
+    # regular tetrahedron of edge a, wish distance b on every edge:
+    # S = 6 (a-b)^2 ; g_i = 2 (a-b)/a * sum_j (x_i - x_j) = 8 (a-b)/a * (x_i - centroid)
+    x = numpy.array([[1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1]], dtype=float)
+    a, b = numpy.sqrt(8.0), 2.0
+    w = numpy.full((4, 4), b)
+    numpy.fill_diagonal(w, 0)
+    s, g = oracle.stress_grad(w, x)
+    assert abs(s - 6 * (a - b) ** 2) < 1e-13
+    assert numpy.allclose(g, 8 * (a - b) / a * (x - x.mean(0)), atol=1e-13)
+
+
+def test_collinear_pair(oracle):
+    x = numpy.array([[0, 0, 0], [3, 0, 0]], dtype=float)
+    w = numpy.array([[0, 1.0], [1.0, 0]])
+    s, g = oracle.stress_grad(w, x)
+    assert s == 4.0 and numpy.array_equal(g, [[-4, 0, 0], [4, 0, 0]])
+
+
+def test_zero_wish_means_no_constraint(oracle):
+    x = _oracle.random_walk(10)
+    s, g = oracle.stress_grad(numpy.zeros((10, 10)), x)
+    assert s == 0 and not g.any()
+
+
+def test_coincident_points_are_finite(oracle):
+    x = numpy.zeros((3, 3))
+    w = numpy.ones((3, 3)) - numpy.eye(3)
+    for f64 in (True, False):
+        s, g = oracle.stress_grad(w, x, f64=f64)
+        assert numpy.isfinite(s) and numpy.isfinite(g).all() and abs(s - 3.0) < 1e-12
+
+
+def test_gradient_matches_finite_differences(oracle):
+    rng = numpy.random.default_rng(5)
+    n = 12
+    x = rng.standard_normal((n, 3))
+    w = _oracle.wish_from_coords(_oracle.random_walk(n, seed=7))
+    w[rng.random((n, n)) < 0.2] = 0
+    w = numpy.triu(w, 1) + numpy.triu(w, 1).T
+    _, g = oracle.stress_grad(w, x)
+    h = 1e-6
+    for i, c in ((0, 0), (5, 1), (11, 2)):
+        xp, xm = x.copy(), x.copy()
+        xp[i, c] += h
+        xm[i, c] -= h
+        fd = (oracle.stress_grad(w, xp)[0] - oracle.stress_grad(w, xm)[0]) / (2 * h)
+        assert abs(fd - g[i, c]) < 1e-6 * max(1.0, abs(g[i, c]))
+
+
+def test_counts_to_wish(oracle):
+    c = numpy.array([[5.0, 8.0, 0.0], [8.0, 1.0, numpy.inf], [0.0, numpy.inf, 2.0]])
+    w = oracle.counts_to_wish(c, alpha=3.0)
+    assert w[0, 1] == w[1, 0] == 8.0 ** (-1.0 / 3.0)
+    assert w[0, 2] == 0 and w[1, 2] == 0 and not numpy.diag(w).any()
+
+
+def test_smacof_step_decreases_stress(oracle):
+    n = 80
+    xs = _oracle.random_walk(n)
+    _, hist = oracle.solve(_oracle.wish_from_coords(xs), _oracle.noisy_init(xs), 15, 1.0 / (2 * n))
+    assert (numpy.diff(hist) < 0).all() and hist[-1] < 0.05 * hist[0]
+
+
+def test_units_partition_sums_to_full(oracle):
+    """Summing the per-unit-range shares over any partition of the device
+    layout's units gives the full lower-triangle result: every pair i<j is
+    owned by exactly one unit (the property the N>1 path relies on)."""
+    from blueberry_amd import _lib
+    lib = _lib.load()
+    n = 300
+    rng = numpy.random.default_rng(3)
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    x = _oracle.noisy_init(xs)
+    s_full, g_full = oracle.stress_grad(w, x)
+    for dtype in (_lib.BB_F32, _lib.BB_F64):
+        info = _lib.LayoutInfo()
+        _lib.check(lib.bb_layout_dense_info(n, dtype, info))
+        ti = numpy.zeros(info.n_tiles, dtype=numpy.int32)
+        tj = numpy.zeros(info.n_tiles, dtype=numpy.int32)
+        _lib.check(lib.bb_layout_dense_tiles(n, dtype, ti.ctypes.data_as(_lib.p_i32),
+                                             tj.ctypes.data_as(_lib.p_i32), info.n_tiles))
+        cuts = sorted(set([0, info.n_units] + list(rng.integers(0, info.n_units, 4))))
+        s_sum, g_sum = 0.0, numpy.zeros_like(x)
+        for a, b in zip(cuts, cuts[1:]):
+            s, g = oracle.stress_grad_units(w, x, ti, tj, info.units_per_tile, info.vw, a, b)
+            s_sum += s
+            g_sum += g
+        assert abs(s_sum - s_full) <= 1e-12 * s_full
+        assert numpy.abs(g_sum - g_full).max() <= 1e-12 * numpy.abs(g_full).max()
