@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py -- pair-updates/s of the 3D-structure solver on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--bins 50000] [--dtype float32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one solver iteration (stress + gradient over every bin pair, then
+the coordinate update) on the workload BASELINE.json's metric is quoted on:
+a dense synthetic N = 50,000-bin wish-distance matrix, fp32, resident in HBM
+(generated on the device from a seeded random walk).
+N GPUs split the SAME matrix (strong scaling): each rank owns a contiguous
+1/N of the packed units and the ranks exchange one all-reduce of the
+(3*n_pad+2)-element gradient buffer per step (RCCL over xGMI).
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel
+(stress_grad_kernel) by its ALGORITHMIC bytes -- 4 B (one fp32 wish distance)
+per pair-update, SURVEY.md 8(d) -- over its HIP-event duration measured on the
+solver's own stream inside the timed region.  `cpu_baseline` times this
+repository's CPU oracle (the reference has no solver to time) on a bounded
+sample, one core.  reference parity: N/A -- path absent in reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--bins", type=int, default=50000)
+    ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-bins", type=int, default=10000)
+    ap.add_argument("--cpu-iters", type=int, default=30)
+    return ap.parse_args()
+
+
+def random_walk(n, seed=0):
+    x = numpy.cumsum(numpy.random.default_rng(seed).standard_normal((n, 3)), axis=0)
+    return x - x.mean(axis=0)
+
+
+def cpu_baseline(n, iters):
+    """The oracle's plain C loop (oracle/bb_oracle.c bbo_solve), one core, on a
+    bounded sample of the same workload shape.  kind = "port": the reference
+    has no solver, so there is no reference binary to time."""
+    from tests import _oracle
+    o = _oracle.load()
+    xs = random_walk(n)
+    w = numpy.empty((n, n))
+    for a in range(0, n, 1000):               # chunked: no (n,n,3) temporary
+        d = xs[a:a + 1000, None, :] - xs[None, :, :]
+        w[a:a + 1000] = numpy.sqrt((d * d).sum(-1))
+    x0 = xs + 0.5 * numpy.random.default_rng(1).standard_normal(xs.shape)
+    t0 = time.perf_counter()
+    o.solve(w, x0, iters, 1.0 / (2 * n), f64=False)
+    dt = time.perf_counter() - t0
+    pairs = n * (n - 1) // 2
+    return {"value": pairs * iters / dt / 1e9, "unit": "Gpair-updates/s", "cores": 1,
+            "kind": "port",
+            "sample": "oracle bbo_solve, N=%d dense, %d iterations, %.1f s, gcc -O2, 1 thread"
+                      % (n, iters, dt)}
+
+
+def pmc_traffic(n_bins, dtype, world):
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3
+    PMC pass on this configuration, or None (profiles/pmc_latest.json)."""
+    p = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        with open(p) as fh:
+            d = json.load(fh)
+        if d.get("bins") == n_bins and d.get("dtype") == dtype and d.get("gpus", 1) == world:
+            return d.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "--nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+
+    torch = dist = None
+    # BB_BENCH_FORCE_DIST=1: run the grad / all-reduce / apply path even with one
+    # rank (rehearses the RCCL plumbing on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("BB_BENCH_FORCE_DIST") == "1"
+    if use_dist:                               # torch is plumbing for the collective only
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from blueberry_amd.solver import HipEngine, allreduce_exchange
+
+    n = a.bins
+    xs = random_walk(n, 0)
+    x0 = xs + 0.5 * numpy.random.default_rng(1).standard_normal(xs.shape)
+    lr = 1.0 / (2 * n)
+    eng = HipEngine(n, a.dtype, rank=rank, world=world, device=local_rank)
+    eng.set_wish_from_coords(xs)          # delta_ij = |x*_i - x*_j| generated in HBM
+    eng.set_coords(x0)
+    exch = eng.exchange_tensor() if use_dist else None
+
+    def steps(k):
+        if not use_dist:
+            eng.iterate(k, lr)
+        else:
+            for _ in range(k):
+                eng.grad()
+                allreduce_exchange(exch)
+                eng.apply(lr)
+
+    def fence():
+        eng.sync()
+        if use_dist:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    steps(a.warmup)
+    fence()
+    eng.set_timing(True)
+    t0 = time.perf_counter()
+    steps(a.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    tim = eng.timing()
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    hist = eng.stress_history()
+    traffic = eng.traffic()
+    eng.close()
+
+    if rank == 0:
+        es = 4 if a.dtype == "float32" else 8
+        pairs = n * (n - 1) // 2
+        value = pairs * a.steps / dt / 1e9
+        # dominant kernel: algorithmic bytes this rank's launch streams / its duration
+        alg_bytes = pairs * es / float(world)
+        achieved = alg_bytes / (tim["grad_ms"] * 1e-3) / 1e9 if tim["grad_ms"] > 0 else 0.0
+        out = {
+            "metric": "Gpair-updates/s per stress iteration, N=50k" if n == 50000 else
+                      "Gpair-updates/s per stress iteration, N=%d" % n,
+            "value": value,
+            "unit": "Gpair-updates/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if a.dtype == "float32" else "f64",
+            "data": "synthetic",
+            "config": {"workload": "dense %d-bin wish-distance matrix from a seeded 3-D random "
+                                   "walk, upper triangle packed in HBM, %s; one stress+gradient+"
+                                   "update iteration per step" % (n, a.dtype),
+                       "bins": n, "pairs_per_step": pairs,
+                       "parallelism": "unit-range sharding x%d + all-reduce(3*n_pad+2)" % world
+                       if world > 1 else "1 gpu"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(n, a.dtype, world),
+                         "kernel": "stress_grad_kernel<%s>" % ("float" if es == 4 else "double"),
+                         "kernel_ms": tim["grad_ms"], "reduce_update_ms": tim["reduce_ms"],
+                         "timed_launches": tim["launches"],
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "resident_bytes_streamed_per_launch": traffic["unit_bytes"]},
+            "stress_first_last": [float(hist[0]), float(hist[-1])] if hist.size else None,
+            "reference_parity": "N/A - path absent in reference; parity is against this "
+                                "repo's CPU oracle (tests/)",
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_bins, a.cpu_iters)
+        print(json.dumps(out))
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,8 @@ SIGNATURES = {
     "bb_solver_exchange_size": (c_int, [c_void_p, p_i64]),
     "bb_solver_get_exchange_buffer": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "bb_solver_set_exchange_buffer": (c_int, [c_void_p, c_void_p]),
+    "bb_solver_read_exchange": (c_int, [c_void_p, p_dbl, c_i64]),
+    "bb_solver_write_exchange": (c_int, [c_void_p, p_dbl, c_i64]),
     "bb_solver_stress": (c_int, [c_void_p, p_dbl]),
     "bb_solver_get_stress_history": (c_int, [c_void_p, p_dbl, c_i64, p_i64]),
     "bb_solver_sync": (c_int, [c_void_p]),
@@ -84,6 +86,21 @@ def load():
         fn.argtypes = argtypes
     _lib = lib
     return lib
+
+
+def hip_runtimes_loaded():
+    """Paths of the libamdhip64 images mapped into this process.  More than one
+    means torch's bundled HIP runtime and the system one are both live, and
+    stream / event handles cannot cross between them (see solver.exchange_tensor)."""
+    paths = set()
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                if "libamdhip64" in line:
+                    paths.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(paths)
 
 
 def last_error():

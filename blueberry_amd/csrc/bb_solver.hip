@@ -990,6 +990,54 @@ int bb_solver_set_exchange_buffer(bb_solver *s, void *dev_ptr) {
     return BB_OK;
 }
 
+int bb_solver_read_exchange(bb_solver *s, double *host, int64_t n) {
+    BB_REQUIRE(s != nullptr && host != nullptr, "bb_solver_read_exchange: NULL argument");
+    BB_REQUIRE(n == 3 * s->L.n_pad + 2, "bb_solver_read_exchange: n != exchange size");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    double *tmp = nullptr;
+    BB_TRY(dev_alloc(&tmp, n));
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (s->dtype == BB_F32)
+        hipLaunchKernelGGL(T_to_f64_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
+                           (const float *)s->d_exch, tmp, n);
+    else
+        hipLaunchKernelGGL(T_to_f64_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
+                           (const double *)s->d_exch, tmp, n);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(host, tmp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    hipFree(tmp);
+    if (e != hipSuccess)
+        return bb::fail(BB_ERR_HIP, std::string("bb_solver_read_exchange: ") + hipGetErrorString(e));
+    return BB_OK;
+}
+
+int bb_solver_write_exchange(bb_solver *s, const double *host, int64_t n) {
+    BB_REQUIRE(s != nullptr && host != nullptr, "bb_solver_write_exchange: NULL argument");
+    BB_REQUIRE(n == 3 * s->L.n_pad + 2, "bb_solver_write_exchange: n != exchange size");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    double *tmp = nullptr;
+    BB_TRY(dev_alloc(&tmp, n));
+    hipError_t e = hipMemcpyAsync(tmp, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice,
+                                  s->stream);
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        if (s->dtype == BB_F32)
+            hipLaunchKernelGGL(f64_to_T_kernel<float>, dim3(grid), dim3(256), 0, s->stream, tmp,
+                               (float *)s->d_exch, n);
+        else
+            hipLaunchKernelGGL(f64_to_T_kernel<double>, dim3(grid), dim3(256), 0, s->stream, tmp,
+                               (double *)s->d_exch, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    hipFree(tmp);
+    if (e != hipSuccess)
+        return bb::fail(BB_ERR_HIP, std::string("bb_solver_write_exchange: ") + hipGetErrorString(e));
+    return BB_OK;
+}
+
 int bb_solver_stress(bb_solver *s, double *stress) {
     BB_TRY(check_ready(s, "bb_solver_stress"));
     BB_REQUIRE(stress != nullptr, "bb_solver_stress: stress is NULL");

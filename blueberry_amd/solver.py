@@ -117,6 +117,23 @@ class HipEngine(object):
     def sync(self):
         _lib.check(self._lib.bb_solver_sync(self._h), "bb_solver_sync")
 
+    def exchange_size(self):
+        n = _lib.c_i64()
+        _lib.check(self._lib.bb_solver_exchange_size(self._h, n), "bb_solver_exchange_size")
+        return int(n.value)
+
+    def read_exchange(self):
+        """Exchange buffer [g (n_pad,3) | stress hi | lo] as float64 on the host."""
+        out = numpy.empty(self.exchange_size(), dtype=numpy.float64)
+        _lib.check(self._lib.bb_solver_read_exchange(self._h, _lib.as_f64_ptr(out), out.size),
+                   "bb_solver_read_exchange")
+        return out
+
+    def write_exchange(self, host):
+        host = numpy.ascontiguousarray(host, dtype=numpy.float64)
+        _lib.check(self._lib.bb_solver_write_exchange(self._h, _lib.as_f64_ptr(host), host.size),
+                   "bb_solver_write_exchange")
+
     # -- the all-reduce boundary (world > 1) --------------------------------
     def exchange_tensor(self):
         """A torch tensor aliasing the exchange buffer [g (n_pad,3) | hi | lo].
@@ -127,6 +144,12 @@ class HipEngine(object):
         the kernels are ordered without host synchronisation."""
         if self._exch is None:
             import torch
+            rts = _lib.hip_runtimes_loaded()
+            if len(rts) > 1:
+                raise RuntimeError(
+                    "two HIP runtimes are loaded (%s): import torch BEFORE the first "
+                    "blueberry_amd compute call in a distributed job, so that "
+                    "libblueberry_hip.so binds to the runtime torch uses" % ", ".join(rts))
             n = _lib.c_i64()
             _lib.check(self._lib.bb_solver_exchange_size(self._h, n), "bb_solver_exchange_size")
             tdt = torch.float32 if self.dtype == "float32" else torch.float64
@@ -177,18 +200,22 @@ def _check_coords(x, n_bins):
 
 
 def allreduce_exchange(t):
-    """Sum the exchange buffer over all ranks, in place.
-
-    backend nccl (= RCCL): one in-place all-reduce of 3*n_pad+2 elements on the
-    device, over xGMI.  backend gloo (CPU rehearsals and tests): staged through
-    host memory -- transport only, the arithmetic on either side is unchanged."""
+    """Sum a device-resident exchange tensor over all ranks, in place: one
+    all-reduce of 3*n_pad+2 elements (backend nccl = RCCL, over xGMI)."""
     import torch.distributed as dist
-    if dist.get_backend() == "nccl" or not t.is_cuda:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    else:
-        host = t.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM)
-        t.copy_(host)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+def allreduce_exchange_host(eng):
+    """The same sum for a host-memory collective (backend gloo: CPU rehearsals,
+    tests, 2 ranks sharing one GPU): read the buffer through the C-ABI, reduce
+    on the host in float64, write it back.  Transport only -- the kernels on
+    either side are the same ones the RCCL path runs."""
+    import torch
+    import torch.distributed as dist
+    host = torch.from_numpy(eng.read_exchange())
+    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+    eng.write_exchange(host.numpy())
 
 
 def _dist_state(distributed):
@@ -308,8 +335,15 @@ def run_iterations(eng, n_iter, lr, world):
     if world == 1:
         eng.iterate(n_iter, lr)
         return
-    t = eng.exchange_tensor()
-    for _ in range(n_iter):
-        eng.grad()
-        allreduce_exchange(t)
-        eng.apply(lr)
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl":
+        t = eng.exchange_tensor()
+        for _ in range(n_iter):
+            eng.grad()
+            allreduce_exchange(t)
+            eng.apply(lr)
+    else:
+        for _ in range(n_iter):
+            eng.grad()
+            allreduce_exchange_host(eng)
+            eng.apply(lr)

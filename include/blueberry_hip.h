@@ -152,6 +152,11 @@ BB_API int bb_solver_apply(bb_solver *s, double lr);
 BB_API int bb_solver_exchange_size(const bb_solver *s, int64_t *n_elems);
 BB_API int bb_solver_get_exchange_buffer(bb_solver *s, void **dev_ptr);
 BB_API int bb_solver_set_exchange_buffer(bb_solver *s, void *dev_ptr);
+/* Host-staged access to the exchange buffer, widened to float64, for callers
+ * whose collective runs on host memory (MPI, gloo): read after bb_solver_grad,
+ * sum over ranks, write back, then bb_solver_apply.  n = bb_solver_exchange_size. */
+BB_API int bb_solver_read_exchange(bb_solver *s, double *host, int64_t n);
+BB_API int bb_solver_write_exchange(bb_solver *s, const double *host, int64_t n);
 
 /* Stress of the current coordinates (one gradient pass, no update). */
 BB_API int bb_solver_stress(bb_solver *s, double *stress);

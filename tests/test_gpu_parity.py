@@ -1,0 +1,305 @@
+"""GPU: the HIP path, called through the C-ABI (ctypes), against the oracle
+and the reference's golden vectors.  Integer / fp64-normalise results are
+bit-exact; the solver is compared within the tolerance BASELINE.json states
+(fp64 1e-12, fp32 1e-5; written at each assert)."""
+import numpy
+import pytest
+
+import blueberry_amd as bb
+from blueberry_amd import _lib
+from blueberry_amd.solver import HipEngine
+from tests import _oracle
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- K1 ---------------------------------------------------------------------
+def band_cases():
+    z = _oracle.golden("band_count")
+    return sorted(k[3:] for k in z.files if k.startswith("in_"))
+
+
+@pytest.mark.parametrize("name", band_cases())
+def test_band_count_golden(name):
+    z = _oracle.golden("band_count")
+    assert bb.count_band_regions(z["in_" + name]) == int(z["out_" + name])
+
+
+@pytest.mark.parametrize("n", [3, 255, 256, 257, 2047, 2048, 2049, 6000])
+def test_band_count_vs_oracle_ragged(oracle, n):
+    rng = numpy.random.default_rng(n)
+    r = numpy.cumsum(rng.integers(1, 60, size=n) * 2500.0)
+    if n % 2:
+        r = rng.permutation(r)          # unsorted input keeps reference semantics
+    assert bb.count_band_regions(r) == oracle.count_band_regions(r)
+
+
+def test_band_count_rows_shares_sum(oracle):
+    r = _oracle.golden("band_count")["in_gappy_n5000"]
+    lib = _lib.load()
+    tot = 0
+    for rank in range(3):
+        a, b = bb.band.band_row_share(r.shape[0], rank, 3)
+        out = _lib.c_i64()
+        _lib.check(lib.bb_band_count_rows(_lib.as_f64_ptr(r), r.shape[0], 25000, 10000000,
+                                          a, b, 0, out))
+        assert out.value == oracle.count_band_regions_rows(r, a, b)
+        tot += out.value
+    assert tot == int(_oracle.golden("band_count")["out_gappy_n5000"])
+
+
+def test_band_count_closed_form_large():
+    # N = 50,000 uniform 5 kb bins: d = 5..2000 bins apart
+    n = 50000
+    r = numpy.arange(n) * 5000.0
+    assert bb.count_band_regions(r) == sum(n - d for d in range(5, 2001))
+
+
+def test_band_count_converts_non_float64():
+    assert bb.count_band_regions(list(range(0, 500000, 50000))) == \
+        bb.count_band_regions(numpy.arange(0, 500000, 50000, dtype=numpy.int32))
+
+
+# ---- A2 / A3 ------------------------------------------------------------------
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_contactmap_golden_bit_exact(k):
+    z = _oracle.golden("contactmap")
+    kr, ke = z["cm%d_krnorm" % k], z["cm%d_krexp" % k]
+    raw = bb.datatypes.scatter_triples(z["cm%d_triples" % k], int(z["cm%d_resolution" % k]),
+                                       kr.shape[0])
+    assert numpy.array_equal(raw, z["cm%d_matrix_raw" % k])
+    cm = bb.ContactMap.from_matrix(raw, resolution=int(z["cm%d_resolution" % k]), KRnorm=kr,
+                                   KRexpected=ke)
+    assert cm.normalize() is None
+    assert numpy.array_equal(cm.matrix, z["cm%d_matrix_norm" % k])
+
+
+def test_contactmap_normalize_vs_oracle_ragged(oracle):
+    rng = numpy.random.default_rng(11)
+    for n_bins in (1, 31, 32, 33, 100, 517):
+        d = n_bins + 1
+        m = rng.integers(0, 50, size=(d, d)).astype(float)
+        m = numpy.triu(m) + numpy.triu(m, 1).T
+        m[:, -1] = numpy.nan            # last row/col: only nan_to_num touches it
+        m[-1, :] = numpy.inf
+        kr = 0.5 + rng.random(n_bins)
+        kr[rng.random(n_bins) < 0.1] = numpy.nan
+        ke = 1.0 + rng.random(n_bins)
+        want = oracle.contactmap_normalize(m, kr, ke)
+        cm = bb.ContactMap.from_matrix(m.copy(), KRnorm=kr, KRexpected=ke)
+        cm.normalize()
+        assert numpy.array_equal(cm.matrix, want), n_bins
+
+
+def test_contactmap_scatter_duplicates_last_wins(oracle):
+    rng = numpy.random.default_rng(12)
+    n_bins, res = 40, 5000
+    bi = rng.integers(0, n_bins, 3000)
+    bj = rng.integers(0, n_bins, 3000)          # many duplicates, both orientations
+    t = numpy.stack([bi * res + 17.0, bj * res + 4000.0, rng.random(3000)], 1)
+    assert numpy.array_equal(bb.datatypes.scatter_triples(t, res, n_bins),
+                             oracle.contactmap_scatter(t, res, n_bins))
+
+
+def test_contactmap_zero_kr_raises_like_reference():
+    cm = bb.ContactMap.from_matrix(numpy.ones((4, 4)), KRnorm=numpy.array([1.0, 0.0, 1.0]),
+                                   KRexpected=numpy.ones(3))
+    with pytest.raises(ZeroDivisionError):
+        cm.normalize()
+
+
+# ---- S0 solver ----------------------------------------------------------------
+def _problem(n, seed=0):
+    xs = _oracle.random_walk(n, seed)
+    return xs, _oracle.wish_from_coords(xs), _oracle.noisy_init(xs)
+
+
+def _rel(a, b):
+    return numpy.abs(a - b).max() / numpy.abs(b).max()
+
+
+def test_solver_fp64_chr21_sized(oracle):
+    """BASELINE config 2: N = 963, fp64, K = 20, tol 1e-12 (relative, on the
+    stress history and on max-abs coordinates) against the CPU oracle."""
+    n, k = 963, 20
+    xs, w, x0 = _problem(n)
+    lr = 1.0 / (2 * n)
+    X_ref, hist_ref = oracle.solve(w, x0, k, lr, f64=True)
+    s = bb.StructureSolver(n_iter=k, lr=lr, dtype="float64", kind="wish").fit(w, init=x0)
+    assert s.stress_.shape == (k,)
+    assert numpy.abs(s.stress_ / hist_ref - 1).max() < 1e-12
+    assert _rel(s.structure_, X_ref) < 1e-12
+
+
+@pytest.mark.parametrize("n", [2, 3, 7, 8, 9, 127, 128, 129, 255, 256, 257, 300, 513])
+def test_solver_ragged_sizes_both_dtypes(oracle, n):
+    xs, w, x0 = _problem(n, seed=n)
+    lr, k = 1.0 / (2 * n), 5
+    X_ref, hist_ref = oracle.solve(w, x0, k, lr, f64=True)
+    for dtype, tol in (("float64", 1e-12), ("float32", 1e-5)):
+        s = bb.StructureSolver(n_iter=k, lr=lr, dtype=dtype, kind="wish").fit(w, init=x0)
+        assert numpy.abs(s.stress_ - hist_ref).max() <= tol * hist_ref.max(), (n, dtype)
+        assert _rel(s.structure_, X_ref) < tol, (n, dtype)
+
+
+def test_solver_fp32_vs_oracle_mid(oracle):
+    """fp32 path at a size the oracle finishes in seconds; tol 1e-5 (BASELINE config 3)."""
+    n, k = 3000, 10
+    xs, w, x0 = _problem(n)
+    lr = 1.0 / (2 * n)
+    X_ref, hist_ref = oracle.solve(w, x0, k, lr, f64=False)
+    s = bb.StructureSolver(n_iter=k, lr=lr, dtype="float32", kind="wish").fit(w, init=x0)
+    assert numpy.abs(s.stress_ / hist_ref - 1).max() < 1e-5
+    assert _rel(s.structure_, X_ref) < 1e-5
+
+
+def test_solver_counts_and_missing_pairs(oracle):
+    """kind='counts': delta = c^(-1/alpha) on the device; zero / inf / nan counts
+    and a zero row carry no constraint."""
+    n, k = 400, 6
+    rng = numpy.random.default_rng(4)
+    xs = _oracle.random_walk(n)
+    d = _oracle.wish_from_coords(xs) + numpy.eye(n)
+    c = d ** -3.0
+    c[rng.random((n, n)) < 0.3] = 0.0
+    c = numpy.triu(c, 1) + numpy.triu(c, 1).T
+    c[5, :] = c[:, 5] = 0.0
+    c[7, 9] = c[9, 7] = numpy.inf
+    c[8, 10] = c[10, 8] = numpy.nan
+    w = oracle.counts_to_wish(numpy.nan_to_num(c, nan=0.0, posinf=numpy.inf), alpha=3.0)
+    x0 = _oracle.noisy_init(xs)
+    lr = 1.0 / (2 * n)
+    X_ref, hist_ref = oracle.solve(w, x0, k, lr)
+    s = bb.StructureSolver(n_iter=k, lr=lr, dtype="float64", kind="counts", alpha=3.0).fit(c, init=x0)
+    assert numpy.abs(s.stress_ / hist_ref - 1).max() < 1e-12
+    assert _rel(s.structure_, X_ref) < 1e-12
+    assert numpy.array_equal(s.structure_[5], x0[5])       # unconstrained bin never moves
+
+
+def test_solver_accepts_contactmap_and_strided_input(oracle):
+    n = 130
+    xs, w, x0 = _problem(n)
+    cm = bb.ContactMap.from_matrix(w)
+    a = bb.StructureSolver(n_iter=3, dtype="float64", kind="wish").fit(cm, init=x0)
+    big = numpy.zeros((n, n + 7))
+    big[:, :n] = w
+    b = bb.StructureSolver(n_iter=3, dtype="float64", kind="wish").fit(big[:, :n], init=x0)
+    assert numpy.array_equal(a.structure_, b.structure_)
+    assert a.lr_ == 1.0 / (2 * n) and a.n_bins_ == n
+
+
+def test_solver_bitwise_reproducible():
+    n = 1500
+    xs, w, x0 = _problem(n)
+    runs = [bb.StructureSolver(n_iter=4, dtype="float32", kind="wish").fit(w, init=x0)
+            for _ in range(2)]
+    assert numpy.array_equal(runs[0].structure_, runs[1].structure_)
+    assert numpy.array_equal(runs[0].stress_, runs[1].stress_)
+
+
+def test_grad_apply_path_equals_iterate():
+    """The two-call path used around the all-reduce gives the same bits as the
+    fused single-rank loop (fp64: exchange carries the gradient unrounded)."""
+    n, k = 700, 4
+    xs, w, x0 = _problem(n)
+    lr = 1.0 / (2 * n)
+    outs = []
+    for two_call in (False, True):
+        e = HipEngine(n, "float64")
+        e.set_wish_dense(w, "wish", 3.0)
+        e.set_coords(x0)
+        if two_call:
+            for _ in range(k):
+                e.grad()
+                e.apply(lr)
+        else:
+            e.iterate(k, lr)
+        outs.append((e.get_coords(), e.stress_history()))
+        e.close()
+    assert numpy.array_equal(outs[0][0], outs[1][0])
+    assert numpy.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_rank_shares_sum_to_full_gradient(oracle, world):
+    """Each rank of a `world`-way job computes the gradient of its own units;
+    the sum over ranks (what the all-reduce produces) is the full gradient."""
+    n = 1000
+    xs, w, x0 = _problem(n)
+    s_ref, g_ref = oracle.stress_grad(w, x0)
+    for dtype, tol in (("float64", 1e-12), ("float32", 2e-6)):
+        g_sum, s_sum = numpy.zeros((n, 3)), 0.0
+        for rank in range(world):
+            e = HipEngine(n, dtype, rank=rank, world=world)
+            e.set_wish_dense(w, "wish", 3.0)
+            e.set_coords(x0)
+            e.grad()
+            e.sync()
+            host = e.read_exchange()
+            g_sum += host[:3 * n].reshape(n, 3)
+            s_sum += float(host[-2]) + float(host[-1])
+            assert not host[3 * n:-2].any()                 # padding bins carry no force
+            e.close()
+        assert abs(s_sum / s_ref - 1) < tol
+        assert numpy.abs(g_sum - g_ref).max() < tol * numpy.abs(g_ref).max()
+
+
+def test_device_generated_wish_equals_host_matrix():
+    n = 777
+    xs, w, x0 = _problem(n)
+    res = []
+    for from_coords in (False, True):
+        e = HipEngine(n, "float64")
+        if from_coords:
+            e.set_wish_from_coords(xs)
+        else:
+            e.set_wish_dense(w, "wish", 3.0)
+        e.set_coords(x0)
+        res.append(e.stress())
+        e.close()
+    assert abs(res[0] / res[1] - 1) < 1e-13
+
+
+def test_full_size_properties_fp32():
+    """At a size the oracle cannot reach quickly (N = 24,926, BASELINE config 3):
+    size-independent properties.  Zero stress and a fixed point at the
+    generating coordinates; monotone decrease from a noisy start (lr = 1/2N is a
+    majorisation step); translation invariance."""
+    n = 24926
+    xs = _oracle.random_walk(n)
+    e = HipEngine(n, "float32")
+    e.set_wish_from_coords(xs)
+    e.set_coords(xs)
+    scale = float((xs ** 2).sum())
+    assert e.stress() < 1e-9 * n * n              # fp32 rounding of delta and d only
+    e.iterate(1, 1.0 / (2 * n))
+    assert numpy.abs(e.get_coords() - xs).max() < 1e-4 * numpy.abs(xs).max()
+    x0 = _oracle.noisy_init(xs)
+    e.set_coords(x0)
+    e.iterate(8, 1.0 / (2 * n))
+    h = e.stress_history()
+    assert (numpy.diff(h) < 0).all() and h[-1] < 0.2 * h[0]
+    s_a = e.stress()
+    moved = e.get_coords() + numpy.array([10.0, -20.0, 5.0])
+    e.set_coords(moved)
+    assert abs(e.stress() / s_a - 1) < 1e-3
+    e.close()
+    assert scale > 0
+
+
+# ---- error behaviour -----------------------------------------------------------
+def test_errors():
+    with pytest.raises(ValueError):
+        bb.StructureSolver().fit(numpy.zeros((3, 4)))
+    with pytest.raises(ValueError):
+        bb.StructureSolver().fit(numpy.zeros((1, 1)))
+    with pytest.raises(ValueError):
+        bb.StructureSolver(dtype="float16")
+    e = HipEngine(10, "float32")
+    with pytest.raises(RuntimeError):
+        e.iterate(1, 0.1)                         # no wish distances / coordinates yet
+    with pytest.raises(ValueError):
+        e.set_coords(numpy.zeros((9, 3)))
+    e.close()
+    with pytest.raises(ValueError):
+        HipEngine(10, "float32", device=99)
