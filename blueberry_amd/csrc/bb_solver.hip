@@ -16,6 +16,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "bb_common.h"
@@ -83,6 +84,41 @@ __device__ __forceinline__ T wave_sum_hi(T v) {
     v += dpp_get<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
     v += dpp_get<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3
     return v;
+}
+
+// The same tree for three fp32 values at once, as one asm block.  Interleaving
+// the three chains puts two independent VALU ops between every write of a
+// register and its next DPP read, which is exactly the 2 wait states that
+// hazard needs (the compiler serialises the chains and pads each step with
+// s_nop), and the two row_bcast steps become single v_add_f32_dpp with a
+// partial row_mask (disabled rows keep their value) instead of mov+mov+add.
+// Only the leading s_nop is needed: the inputs were just written by VALU code.
+__device__ __forceinline__ void wave_sum_hi3(float &a, float &b, float &c) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(a), "+v"(b), "+v"(c));
+}
+__device__ __forceinline__ void wave_sum_hi3(double &a, double &b, double &c) {
+    a = wave_sum_hi(a);
+    b = wave_sum_hi(b);
+    c = wave_sum_hi(c);
 }
 
 // Value of `v` in lane `l` (compile-time l) as a wave-uniform scalar.
@@ -183,9 +219,7 @@ __device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[kRowsP
             pair_step<T, 3>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
         }
         d[r] = next[r * 64];
-        gx = wave_sum_hi(gx);
-        gy = wave_sum_hi(gy);
-        gz = wave_sum_hi(gz);
+        wave_sum_hi3(gx, gy, gz);
         // one 3-element store per matrix row, from the lane holding the sums
         store_row3(row_rsrc, row_voff + r * 3 * (unsigned)sizeof(T), gx, gy, gz);
         // keep the rows in program order: otherwise the scheduler interleaves all
@@ -193,6 +227,84 @@ __device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[kRowsP
         __builtin_amdgcn_sched_barrier(0);
     }
     stress += (double)s;
+}
+
+// ---- fp32: the same unit with explicit 2-wide packed math (v_pk_*_f32) -------
+// Pairs (0,1) and (2,3) of a lane's four columns share every instruction that
+// has a packed form; column-side state is kept as [component][pair] so that
+// the two pairs sit in adjacent registers.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct StripF32 {
+    f32x2 x[2][3];  // [half][component]: coordinates of columns {0,1} and {2,3}
+    f32x2 g[2][3];  // column-side gradient accumulators, same shape
+};
+
+template <int H>
+__device__ __forceinline__ void pair_step2(f32x2 delta, f32x2 xi, f32x2 yi, f32x2 zi, StripF32 &st,
+                                           f32x2 &rx, f32x2 &ry, f32x2 &rz, f32x2 &s2) {
+    const f32x2 dx = xi - st.x[H][0], dy = yi - st.x[H][1], dz = zi - st.x[H][2];
+    f32x2 d2 = dx * dx + dy * dy + dz * dz;
+    d2.x = fmaxf(d2.x, 1e-30f);
+    d2.y = fmaxf(d2.y, 1e-30f);
+    f32x2 rinv;
+    rinv.x = __builtin_amdgcn_rsqf(d2.x);
+    rinv.y = __builtin_amdgcn_rsqf(d2.y);
+    f32x2 res = d2 * rinv - delta;  // dist - delta
+    res.x = delta.x > 0.f ? res.x : 0.f;
+    res.y = delta.y > 0.f ? res.y : 0.f;
+    s2 += res * res;
+    const f32x2 coef = res * rinv;
+    if constexpr (H == 0) {
+        rx = coef * dx; ry = coef * dy; rz = coef * dz;
+    } else {
+        rx += coef * dx; ry += coef * dy; rz += coef * dz;
+    }
+    st.g[H][0] -= coef * dx;
+    st.g[H][1] -= coef * dy;
+    st.g[H][2] -= coef * dz;
+}
+
+__device__ __forceinline__ void process_unit_f32(float4 (&d)[kRowsPerUnit], float xrow,
+                                                 const float4 *__restrict__ next, StripF32 &st,
+                                                 double &stress, __amdgpu_buffer_rsrc_t row_rsrc,
+                                                 unsigned row_voff) {
+    f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < kRowsPerUnit; ++r) {
+        const float xs = lane_value(xrow, 3 * r), ys = lane_value(xrow, 3 * r + 1),
+                    zs = lane_value(xrow, 3 * r + 2);
+        const f32x2 xi = {xs, xs}, yi = {ys, ys}, zi = {zs, zs};
+        f32x2 rx, ry, rz;
+        pair_step2<0>(f32x2{d[r].x, d[r].y}, xi, yi, zi, st, rx, ry, rz, s2);
+        pair_step2<1>(f32x2{d[r].z, d[r].w}, xi, yi, zi, st, rx, ry, rz, s2);
+        d[r] = next[r * 64];
+        float gx = rx.x + rx.y, gy = ry.x + ry.y, gz = rz.x + rz.y;
+        wave_sum_hi3(gx, gy, gz);
+        store_row3(row_rsrc, row_voff + r * 12u, gx, gy, gz);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    stress += (double)(s2.x + s2.y);
+}
+
+__device__ __forceinline__ void load_strip_f32(StripF32 &st, const float *__restrict__ X, int j0,
+                                               int lane) {
+    const float4 *p = reinterpret_cast<const float4 *>(X + ((int64_t)j0 + (int64_t)lane * 4) * 3);
+    const float4 a = p[0], b = p[1], c = p[2];  // x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3
+    st.x[0][0] = f32x2{a.x, a.w}; st.x[0][1] = f32x2{a.y, b.x}; st.x[0][2] = f32x2{a.z, b.y};
+    st.x[1][0] = f32x2{b.z, c.y}; st.x[1][1] = f32x2{b.w, c.z}; st.x[1][2] = f32x2{c.x, c.w};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) st.g[h][c3] = f32x2{0.f, 0.f};
+}
+
+__device__ __forceinline__ void store_strip_f32(const StripF32 &st, float *__restrict__ slot,
+                                                int lane) {
+    float4 *p = reinterpret_cast<float4 *>(slot + (int64_t)lane * 12);
+    p[0] = make_float4(st.g[0][0].x, st.g[0][1].x, st.g[0][2].x, st.g[0][0].y);
+    p[1] = make_float4(st.g[0][1].y, st.g[0][2].y, st.g[1][0].x, st.g[1][1].x);
+    p[2] = make_float4(st.g[1][2].x, st.g[1][0].y, st.g[1][1].y, st.g[1][2].y);
 }
 
 template <typename T>
@@ -258,15 +370,31 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(GradParams<T> p) {
 
     if (ua < ub) {
         int slot = p.wave_slot[w];
-        T xj[VPL][3], gc[VPL][3];
         Vec d[kRowsPerUnit];
+        // column-strip state: coordinates + gradient accumulators of this lane's columns
+        struct Generic { T xj[VPL][3], gc[VPL][3]; };
+        using Strip = typename std::conditional<sizeof(T) == 4, StripF32, Generic>::type;
+        Strip st;
+        auto strip_load = [&](int j0) __attribute__((always_inline)) {
+            if constexpr (sizeof(T) == 4) {
+                load_strip_f32(st, p.X, j0, lane);
+            } else {
+                load_strip<T>(st.xj, p.X, j0, lane);
+#pragma unroll
+                for (int c = 0; c < VPL; ++c) st.gc[c][0] = st.gc[c][1] = st.gc[c][2] = T(0);
+            }
+        };
+        auto strip_store = [&](int sl) __attribute__((always_inline)) {
+            if constexpr (sizeof(T) == 4)
+                store_strip_f32(st, p.colpart + (int64_t)sl * (3 * VW), lane);
+            else
+                store_strip<T>(st.gc, p.colpart + (int64_t)sl * (3 * VW), lane);
+        };
 
         int2 dc = p.udesc[ua];                             // current unit
         int2 dn = p.udesc[ua + 1 < ub ? ua + 1 : ub - 1];  // next unit
         int curj = dc.y;
-        load_strip<T>(xj, p.X, curj, lane);
-#pragma unroll
-        for (int c = 0; c < VPL; ++c) gc[c][0] = gc[c][1] = gc[c][2] = T(0);
+        strip_load(curj);
         {
             const Vec *first = unit_ptr<T>(p.units, ua, lane);
 #pragma unroll
@@ -285,21 +413,23 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(GradParams<T> p) {
             const T xrn = load_xrow<T>(p.X, dn.x, lane);
             const int2 dnn = p.udesc[u + 2 < ub ? u + 2 : ub - 1];
             if (dc.y != curj) {  // wave-uniform: the sweep enters a new column strip
-                store_strip<T>(gc, p.colpart + (int64_t)slot * (3 * VW), lane);
+                strip_store(slot);
                 ++slot;
                 curj = dc.y;
-                load_strip<T>(xj, p.X, curj, lane);
-#pragma unroll
-                for (int c = 0; c < VPL; ++c) gc[c][0] = gc[c][1] = gc[c][2] = T(0);
+                strip_load(curj);
             }
             const unsigned row_voff = lane == 63 ? (unsigned)(u - ua) * kRowBytes : kDropOffset;
-            process_unit<T>(d, xr, unit_ptr<T>(p.units, un, lane), xj, gc, stress, row_rsrc,
-                            row_voff);
+            if constexpr (sizeof(T) == 4)
+                process_unit_f32(d, xr, unit_ptr<T>(p.units, un, lane), st, stress, row_rsrc,
+                                 row_voff);
+            else
+                process_unit<T>(d, xr, unit_ptr<T>(p.units, un, lane), st.xj, st.gc, stress,
+                                row_rsrc, row_voff);
             xr = xrn;
             dc = dn;
             dn = dnn;
         }
-        store_strip<T>(gc, p.colpart + (int64_t)slot * (3 * VW), lane);
+        strip_store(slot);
     }
 
     // per-wave stress (fixed shuffle tree)
@@ -311,7 +441,12 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(GradParams<T> p) {
 // --------------------------------------------------------------------------
 // reduce (+ update) kernel: one workgroup per vw-bin block
 // --------------------------------------------------------------------------
-enum ReduceMode { kReduceApply = 0, kReduceExchange = 1, kReduceStressOnly = 2 };
+enum ReduceMode {
+    kReduceApply = 0,      // X -= lr * 2 * sum
+    kReduceExchange = 1,   // exch = 2 * sum (+ stress hi/lo)
+    kReduceStressOnly = 2, // stress only
+    kReducePartial = 3     // stage 1: raw sum of one slice of a block's chunk list
+};
 
 template <typename T>
 struct ReduceParams {
@@ -321,6 +456,7 @@ struct ReduceParams {
     const double *__restrict__ stresspart;
     T *__restrict__ X;                       // apply mode
     T *__restrict__ exch;                    // exchange mode: [3*n_pad | hi | lo]
+    T *__restrict__ part_out;                // partial mode: CH elements per workgroup
     double *__restrict__ stress_out;         // apply / stress-only: where the stress goes
     int64_t n_pad;
     int n_waves;
@@ -339,7 +475,25 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
         T acc[NE];
 #pragma unroll
         for (int j = 0; j < NE; ++j) acc[j] = T(0);
-        for (int64_t k = k0; k < k1; ++k) {
+        // chunks are summed in list order (deterministic); 4 chunks = 4*NE loads in flight
+        int64_t k = k0;
+        for (; k + 4 <= k1; k += 4) {
+            const T *s0 = p.part + p.blk_chunk[k], *s1 = p.part + p.blk_chunk[k + 1],
+                    *s2 = p.part + p.blk_chunk[k + 2], *s3 = p.part + p.blk_chunk[k + 3];
+            T v0[NE], v1[NE], v2[NE], v3[NE];
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int e = tid + 256 * j;
+                const bool ok = e < CH;
+                v0[j] = ok ? s0[e] : T(0);
+                v1[j] = ok ? s1[e] : T(0);
+                v2[j] = ok ? s2[e] : T(0);
+                v3[j] = ok ? s3[e] : T(0);
+            }
+#pragma unroll
+            for (int j = 0; j < NE; ++j) acc[j] = (((acc[j] + v0[j]) + v1[j]) + v2[j]) + v3[j];
+        }
+        for (; k < k1; ++k) {
             const T *src = p.part + p.blk_chunk[k];
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
@@ -351,15 +505,20 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
         for (int j = 0; j < NE; ++j) {
             const int e = tid + 256 * j;
             if (e < CH) {
-                const T g = T(2) * acc[j];
                 const int64_t o = (int64_t)b * CH + e;
-                if (p.mode == kReduceApply)
-                    p.X[o] -= p.lr * g;
-                else
-                    p.exch[o] = g;
+                if (p.mode == kReducePartial) {
+                    p.part_out[o] = acc[j];
+                } else {
+                    const T g = T(2) * acc[j];
+                    if (p.mode == kReduceApply)
+                        p.X[o] -= p.lr * g;
+                    else
+                        p.exch[o] = g;
+                }
             }
         }
     }
+    if (p.mode == kReducePartial) return;
     if (b == 0) {
         __shared__ double sh[256];
         double s = 0.0;
@@ -476,7 +635,9 @@ struct bb_solver {
     int64_t *d_wave_begin = nullptr;
     int32_t *d_wave_slot = nullptr;
     double *d_stresspart = nullptr;
-    int64_t *d_blk_ptr = nullptr, *d_blk_chunk = nullptr;
+    int64_t *d_blk_ptr = nullptr, *d_blk_chunk = nullptr;    // final stage: one list per block
+    int64_t *d_s1_ptr = nullptr, *d_s1_chunk = nullptr;      // stage 1: slices of long lists
+    int64_t n_slices = 0, part2_off = 0;
     double *d_stress_hist = nullptr, *d_stress_scalar = nullptr;
     double *d_f64_tmp = nullptr;  // (n_pad,3) staging for coordinate I/O
     int64_t rowpart_elems = 0, colpart_elems = 0;
@@ -579,16 +740,43 @@ int build_indices(bb_solver *s) {
     for (int sl = 0; sl < s->n_slots; ++sl)
         blk_chunk[fill[slot_strip[sl]]++] = s->rowpart_elems + (int64_t)sl * ch;
 
+    // Two-stage reduce: a block's list can hold hundreds of chunks (one per strip
+    // of its tile row).  Lists longer than kSlice are cut into slices that stage 1
+    // sums in parallel into `part2`; the final stage then sums the slice results.
+    constexpr int64_t kSlice = 16;
+    std::vector<int64_t> s1_ptr(1, 0), s1_chunk, fin_ptr(nb + 1, 0), fin_chunk;
+    s->part2_off = s->rowpart_elems + s->colpart_elems;
+    for (int64_t b = 0; b < nb; ++b) {
+        const int64_t k0 = blk_ptr[b], k1 = blk_ptr[b + 1];
+        if (k1 - k0 <= kSlice) {
+            for (int64_t k = k0; k < k1; ++k) fin_chunk.push_back(blk_chunk[k]);
+        } else {
+            for (int64_t k = k0; k < k1; k += kSlice) {
+                const int64_t ke = std::min(k + kSlice, k1);
+                fin_chunk.push_back(s->part2_off + (int64_t)(s1_ptr.size() - 1) * ch);
+                for (int64_t q = k; q < ke; ++q) s1_chunk.push_back(blk_chunk[q]);
+                s1_ptr.push_back((int64_t)s1_chunk.size());
+            }
+        }
+        fin_ptr[b + 1] = (int64_t)fin_chunk.size();
+    }
+    s->n_slices = (int64_t)s1_ptr.size() - 1;
+    if (s1_chunk.empty()) s1_chunk.push_back(0);
+    if (fin_chunk.empty()) fin_chunk.push_back(0);
+    const int64_t part_total = s->part2_off + s->n_slices * ch;
+
     const int64_t es = bb::elem_size(s->dtype);
     BB_TRY(dev_alloc((char **)&s->d_units, std::max<int64_t>(s->n_local, 1) * bb::kUnitBytes));
     BB_TRY(dev_alloc((char **)&s->d_X, s->L.n_pad * 3 * es));
-    BB_TRY(dev_alloc((char **)&s->d_part, (s->rowpart_elems + s->colpart_elems) * es));
+    BB_TRY(dev_alloc((char **)&s->d_part, part_total * es));
     BB_TRY(dev_alloc(&s->d_udesc, (int64_t)s->udesc.size()));
     BB_TRY(dev_alloc(&s->d_wave_begin, nw + 1));
     BB_TRY(dev_alloc(&s->d_wave_slot, nw));
     BB_TRY(dev_alloc(&s->d_stresspart, nw));
     BB_TRY(dev_alloc(&s->d_blk_ptr, nb + 1));
-    BB_TRY(dev_alloc(&s->d_blk_chunk, (int64_t)blk_chunk.size()));
+    BB_TRY(dev_alloc(&s->d_blk_chunk, (int64_t)fin_chunk.size()));
+    BB_TRY(dev_alloc(&s->d_s1_ptr, (int64_t)s1_ptr.size()));
+    BB_TRY(dev_alloc(&s->d_s1_chunk, (int64_t)s1_chunk.size()));
     BB_TRY(dev_alloc(&s->d_stress_hist, kHistCap));
     BB_TRY(dev_alloc(&s->d_stress_scalar, 1));
     BB_TRY(dev_alloc(&s->d_f64_tmp, s->L.n_pad * 3));
@@ -603,12 +791,16 @@ int build_indices(bb_solver *s) {
                                 hipMemcpyHostToDevice, st));
     BB_HIP_CHECK(hipMemcpyAsync(s->d_wave_slot, wave_slot.data(), nw * sizeof(int32_t),
                                 hipMemcpyHostToDevice, st));
-    BB_HIP_CHECK(hipMemcpyAsync(s->d_blk_ptr, blk_ptr.data(), (nb + 1) * sizeof(int64_t),
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_blk_ptr, fin_ptr.data(), (nb + 1) * sizeof(int64_t),
                                 hipMemcpyHostToDevice, st));
-    BB_HIP_CHECK(hipMemcpyAsync(s->d_blk_chunk, blk_chunk.data(),
-                                blk_chunk.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_blk_chunk, fin_chunk.data(),
+                                fin_chunk.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_s1_ptr, s1_ptr.data(), s1_ptr.size() * sizeof(int64_t),
+                                hipMemcpyHostToDevice, st));
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_s1_chunk, s1_chunk.data(),
+                                s1_chunk.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
     // rows of boundary tiles owned by another rank are never written: keep them 0
-    BB_HIP_CHECK(hipMemsetAsync(s->d_part, 0, (size_t)(s->rowpart_elems + s->colpart_elems) * es, st));
+    BB_HIP_CHECK(hipMemsetAsync(s->d_part, 0, (size_t)part_total * es, st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_X, 0, (size_t)(s->L.n_pad * 3 * es), st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_exch, 0, (size_t)((3 * s->L.n_pad + 2) * es), st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_stresspart, 0, (size_t)nw * sizeof(double), st));
@@ -637,16 +829,24 @@ template <typename T>
 int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out) {
     ReduceParams<T> p;
     p.part = (const T *)s->d_part;
-    p.blk_ptr = s->d_blk_ptr;
-    p.blk_chunk = s->d_blk_chunk;
     p.stresspart = s->d_stresspart;
     p.X = (T *)s->d_X;
     p.exch = (T *)s->d_exch;
+    p.part_out = (T *)s->d_part + s->part2_off;
     p.stress_out = stress_out;
     p.n_pad = s->L.n_pad;
     p.n_waves = s->n_waves;
-    p.mode = mode;
     p.lr = (T)lr;
+    if (mode != kReduceStressOnly && s->n_slices > 0) {
+        p.blk_ptr = s->d_s1_ptr;
+        p.blk_chunk = s->d_s1_chunk;
+        p.mode = kReducePartial;
+        hipLaunchKernelGGL(reduce_kernel<T>, dim3((unsigned)s->n_slices), dim3(256), 0, s->stream, p);
+        BB_HIP_CHECK(hipGetLastError());
+    }
+    p.blk_ptr = s->d_blk_ptr;
+    p.blk_chunk = s->d_blk_chunk;
+    p.mode = mode;
     const int grid = mode == kReduceStressOnly ? 1 : (int)s->L.n_blocks;
     hipLaunchKernelGGL(reduce_kernel<T>, dim3(grid), dim3(256), 0, s->stream, p);
     BB_HIP_CHECK(hipGetLastError());
@@ -807,6 +1007,8 @@ int bb_solver_destroy(bb_solver *s) {
     hipFree(s->d_stresspart);
     hipFree(s->d_blk_ptr);
     hipFree(s->d_blk_chunk);
+    hipFree(s->d_s1_ptr);
+    hipFree(s->d_s1_chunk);
     hipFree(s->d_stress_hist);
     hipFree(s->d_stress_scalar);
     hipFree(s->d_f64_tmp);
