@@ -155,6 +155,7 @@ def main():
 
     hist = eng.stress_history()
     traffic = eng.traffic()
+    read_ms = eng.stream_read_ms(10) if a.dtype == "float32" else None
     eng.close()
 
     if rank == 0:
@@ -191,7 +192,13 @@ def main():
                          "kernel_ms": tim["grad_ms"], "reduce_update_ms": tim["reduce_ms"],
                          "timed_launches": tim["launches"],
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "resident_bytes_streamed_per_launch": traffic["unit_bytes"]},
+                         "resident_bytes_streamed_per_launch": traffic["unit_bytes"],
+                         # a read-only sweep of the same units by the same grid on this box
+                         "stream_read_ms": read_ms,
+                         "stream_read_GBs": (traffic["unit_bytes"] / (read_ms * 1e-3) / 1e9
+                                             if read_ms else None),
+                         "frac_of_stream_read": (read_ms / tim["grad_ms"]
+                                                 if read_ms and tim["grad_ms"] > 0 else None)},
             "stress_first_last": [float(hist[0]), float(hist[-1])] if hist.size else None,
             "reference_parity": "N/A - path absent in reference; parity is against this "
                                 "repo's CPU oracle (tests/)",

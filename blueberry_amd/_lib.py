@@ -61,6 +61,7 @@ SIGNATURES = {
     "bb_solver_sync": (c_int, [c_void_p]),
     "bb_solver_set_timing": (c_int, [c_void_p, c_int]),
     "bb_solver_get_timing": (c_int, [c_void_p, p_dbl, p_dbl, p_i64]),
+    "bb_solver_measure_stream_read": (c_int, [c_void_p, c_int, p_dbl]),
     "bb_solver_traffic": (c_int, [c_void_p, p_i64, p_i64]),
     "bb_contactmap_scatter": (c_int, [p_dbl, c_i64, c_i32, p_dbl, c_i64, c_int]),
     "bb_contactmap_normalize": (c_int, [p_dbl, c_i64, p_dbl, p_dbl, c_int]),

@@ -158,19 +158,6 @@ __device__ __forceinline__ void store_row3(__amdgpu_buffer_rsrc_t rsrc, unsigned
 // --------------------------------------------------------------------------
 // stress + gradient kernel
 // --------------------------------------------------------------------------
-template <typename T>
-struct GradParams {
-    const T *__restrict__ units;             // this rank's units, 8*VW elements each
-    const T *__restrict__ X;                 // (n_pad, 3)
-    const int2 *__restrict__ udesc;          // per local unit: {i0, j0}
-    const int64_t *__restrict__ wave_begin;  // n_waves + 1 local unit indices
-    const int32_t *__restrict__ wave_slot;   // first column-partial slot of each wave
-    T *__restrict__ rowpart;                 // 24 elements per unit, tile-aligned base
-    T *__restrict__ colpart;                 // 3*VW elements per slot
-    double *__restrict__ stresspart;         // one per wave
-    int64_t row_shift;                       // u_begin - t_first * units_per_tile
-};
-
 // Pair math for one matrix row of a unit: VPL pairs per lane.
 template <typename T, int C>
 __device__ __forceinline__ void pair_step(const typename Traits<T>::Vec &drow, T xi, T yi, T zi,
@@ -196,10 +183,33 @@ __device__ __forceinline__ void pair_step(const typename Traits<T>::Vec &drow, T
     gc[C][0] -= fx; gc[C][1] -= fy; gc[C][2] -= fz;
 }
 
+// Matrix rows are read exactly once per launch: NT = true marks the loads
+// non-temporal so the stream does not evict X and the partials from L2 / MALL.
+typedef float f32x4_raw __attribute__((ext_vector_type(4)));
+typedef double f64x2_raw __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ float4 stream_load(const float4 *p) {
+    if constexpr (NT) {
+        const f32x4_raw v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_raw *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ double2 stream_load(const double2 *p) {
+    if constexpr (NT) {
+        const f64x2_raw v = __builtin_nontemporal_load(reinterpret_cast<const f64x2_raw *>(p));
+        return make_double2(v.x, v.y);
+    } else {
+        return *p;
+    }
+}
+
 // One unit (8 matrix rows).  Row r of the CURRENT unit is consumed from d[r],
 // then d[r] is immediately refilled with row r of the NEXT unit, so 8 KiB per
 // wave stay in flight with a single 8-row register buffer.
-template <typename T>
+template <typename T, bool NT>
 __device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[kRowsPerUnit], T xrow,
                                              const typename Traits<T>::Vec *__restrict__ next,
                                              const T (&xj)[Traits<T>::VPL][3],
@@ -218,7 +228,7 @@ __device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[kRowsP
             pair_step<T, 2>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
             pair_step<T, 3>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
         }
-        d[r] = next[r * 64];
+        d[r] = stream_load<NT>(next + r * 64);
         wave_sum_hi3(gx, gy, gz);
         // one 3-element store per matrix row, from the lane holding the sums
         store_row3(row_rsrc, row_voff + r * 3 * (unsigned)sizeof(T), gx, gy, gz);
@@ -265,6 +275,7 @@ __device__ __forceinline__ void pair_step2(f32x2 delta, f32x2 xi, f32x2 yi, f32x
     st.g[H][2] -= coef * dz;
 }
 
+template <bool NT>
 __device__ __forceinline__ void process_unit_f32(float4 (&d)[kRowsPerUnit], float xrow,
                                                  const float4 *__restrict__ next, StripF32 &st,
                                                  double &stress, __amdgpu_buffer_rsrc_t row_rsrc,
@@ -278,7 +289,7 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[kRowsPerUnit], floa
         f32x2 rx, ry, rz;
         pair_step2<0>(f32x2{d[r].x, d[r].y}, xi, yi, zi, st, rx, ry, rz, s2);
         pair_step2<1>(f32x2{d[r].z, d[r].w}, xi, yi, zi, st, rx, ry, rz, s2);
-        d[r] = next[r * 64];
+        d[r] = stream_load<NT>(next + r * 64);
         float gx = rx.x + rx.y, gy = ry.x + ry.y, gz = rz.x + rz.y;
         wave_sum_hi3(gx, gy, gz);
         store_row3(row_rsrc, row_voff + r * 12u, gx, gy, gz);
@@ -356,20 +367,39 @@ __device__ __forceinline__ void store_strip(const T (&gc)[Traits<T>::VPL][3],
     }
 }
 
-// One wave = one contiguous chunk of units; 4 independent waves per workgroup.
-// No LDS, no barriers, no atomics: results are bitwise reproducible.
-template <typename T>
-__global__ __launch_bounds__(256, 4) void stress_grad_kernel(GradParams<T> p) {
+// `stride` consecutive waves share one contiguous chunk of units and take its
+// units round-robin (wave k of the group: first+k, first+k+stride, ...), so the
+// group streams one contiguous window of HBM together; 4 independent waves per
+// workgroup.  No LDS, no barriers, no atomics: results are bitwise reproducible.
+//
+// Arguments are separate __restrict__ pointers (not a struct) so that the
+// read-only index arrays are provably unclobbered and load through the scalar
+// cache.  Unit indices are 32-bit (a rank holds < 2^31 units = 16 TiB).
+//   units      this rank's units, 8*VW elements each
+//   X          (n_pad, 3) coordinates
+//   udesc      per local unit {i0, j0}
+//   wave_range per wave {first, end} local unit indices
+//   wave_slot  first column-partial slot of each wave
+//   rowpart    24 elements per unit, base shifted to the rank's first tile
+//   colpart    3*VW elements per slot
+//   stresspart one double per wave
+template <typename T, bool NT>
+__global__ __launch_bounds__(256, 4) void stress_grad_kernel(
+    const T *__restrict__ units, const T *__restrict__ X, const int2 *__restrict__ udesc,
+    const int2 *__restrict__ wave_range, const int32_t *__restrict__ wave_slot,
+    T *__restrict__ rowpart, T *__restrict__ colpart, double *__restrict__ stresspart,
+    int stride) {
     using Vec = typename Traits<T>::Vec;
     constexpr int VPL = Traits<T>::VPL;
     constexpr int VW = Traits<T>::VW;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int64_t ua = p.wave_begin[w], ub = p.wave_begin[w + 1];
+    const int2 range = wave_range[w];
+    const int ua = range.x, ub = range.y;
     double stress = 0.0;
 
     if (ua < ub) {
-        int slot = p.wave_slot[w];
+        int slot = wave_slot[w];
         Vec d[kRowsPerUnit];
         // column-strip state: coordinates + gradient accumulators of this lane's columns
         struct Generic { T xj[VPL][3], gc[VPL][3]; };
@@ -377,65 +407,78 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(GradParams<T> p) {
         Strip st;
         auto strip_load = [&](int j0) __attribute__((always_inline)) {
             if constexpr (sizeof(T) == 4) {
-                load_strip_f32(st, p.X, j0, lane);
+                load_strip_f32(st, X, j0, lane);
             } else {
-                load_strip<T>(st.xj, p.X, j0, lane);
+                load_strip<T>(st.xj, X, j0, lane);
 #pragma unroll
                 for (int c = 0; c < VPL; ++c) st.gc[c][0] = st.gc[c][1] = st.gc[c][2] = T(0);
             }
         };
         auto strip_store = [&](int sl) __attribute__((always_inline)) {
             if constexpr (sizeof(T) == 4)
-                store_strip_f32(st, p.colpart + (int64_t)sl * (3 * VW), lane);
+                store_strip_f32(st, colpart + (int64_t)sl * (3 * VW), lane);
             else
-                store_strip<T>(st.gc, p.colpart + (int64_t)sl * (3 * VW), lane);
+                store_strip<T>(st.gc, colpart + (int64_t)sl * (3 * VW), lane);
         };
 
-        int2 dc = p.udesc[ua];                             // current unit
-        int2 dn = p.udesc[ua + 1 < ub ? ua + 1 : ub - 1];  // next unit
-        int curj = dc.y;
-        strip_load(curj);
+        int2 dc = udesc[ua];                                   // current unit
+        int2 dn = udesc[ua + stride < ub ? ua + stride : ua];  // next unit
+        // Prologue: the x rows of the first unit, then its 8 matrix rows.
+        T xr = load_xrow<T>(X, dc.x, lane);
         {
-            const Vec *first = unit_ptr<T>(p.units, ua, lane);
+            const Vec *first = unit_ptr<T>(units, ua, lane);
 #pragma unroll
-            for (int r = 0; r < kRowsPerUnit; ++r) d[r] = first[r * 64];
+            for (int r = 0; r < kRowsPerUnit; ++r) d[r] = stream_load<NT>(first + r * 64);
         }
-        T xr = load_xrow<T>(p.X, dc.x, lane);
-        // this wave's row partials: 24 elements per unit
+        // this wave's row partials: 24 elements per unit of its group's chunk
         constexpr unsigned kRowBytes = 3 * kRowsPerUnit * sizeof(T);
         const __amdgpu_buffer_rsrc_t row_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            p.rowpart + (ua + p.row_shift) * (3 * kRowsPerUnit), 0, (int)((ub - ua) * kRowBytes),
+            rowpart + (int64_t)ua * (3 * kRowsPerUnit), 0, (int)((unsigned)(ub - ua) * kRowBytes),
             0x00020000);
 
-        for (int64_t u = ua; u < ub; ++u) {
+        auto unit_step = [&](int u) __attribute__((always_inline)) {
             // the wave's last unit "prefetches" itself: harmless, stays in bounds
-            const int64_t un = u + 1 < ub ? u + 1 : ub - 1;
-            const T xrn = load_xrow<T>(p.X, dn.x, lane);
-            const int2 dnn = p.udesc[u + 2 < ub ? u + 2 : ub - 1];
-            if (dc.y != curj) {  // wave-uniform: the sweep enters a new column strip
-                strip_store(slot);
-                ++slot;
-                curj = dc.y;
-                strip_load(curj);
-            }
+            const int un = u + stride < ub ? u + stride : u;
+            const T xrn = load_xrow<T>(X, dn.x, lane);
+            const int2 dnn = udesc[un + stride < ub ? un + stride : un];
             const unsigned row_voff = lane == 63 ? (unsigned)(u - ua) * kRowBytes : kDropOffset;
             if constexpr (sizeof(T) == 4)
-                process_unit_f32(d, xr, unit_ptr<T>(p.units, un, lane), st, stress, row_rsrc,
-                                 row_voff);
+                process_unit_f32<NT>(d, xr, unit_ptr<T>(units, un, lane), st, stress, row_rsrc,
+                                     row_voff);
             else
-                process_unit<T>(d, xr, unit_ptr<T>(p.units, un, lane), st.xj, st.gc, stress,
-                                row_rsrc, row_voff);
+                process_unit<T, NT>(d, xr, unit_ptr<T>(units, un, lane), st.xj, st.gc, stress,
+                                    row_rsrc, row_voff);
             xr = xrn;
             dc = dn;
             dn = dnn;
+        };
+        // Outer loop: one trip per column strip the wave's sweep crosses (rare).
+        // Inner loop: the units of that strip, with NO branch in the body.  Its
+        // first unit is peeled, so the inner loop is only ever entered from a
+        // state with the loop body's own pattern of outstanding loads and
+        // stores: hipcc's s_waitcnt counts are static and are merged over every
+        // entry of a loop header, and a prologue- or strip-change-shaped entry
+        // drains most of the 8-row prefetch window on every iteration.
+        int u = ua;
+        for (;;) {
+            const int curj = dc.y;
+            strip_load(curj);
+            unit_step(u);
+            u += stride;
+            while (u < ub && dc.y == curj) {
+                unit_step(u);
+                u += stride;
+            }
+            strip_store(slot);
+            ++slot;
+            if (u >= ub) break;
         }
-        strip_store(slot);
     }
 
     // per-wave stress (fixed shuffle tree)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) stress += __shfl_down(stress, off, 64);
-    if (lane == 0) p.stresspart[w] = stress;
+    if (lane == 0) stresspart[w] = stress;
 }
 
 // --------------------------------------------------------------------------
@@ -602,6 +645,37 @@ __global__ __launch_bounds__(256) void gen_units_kernel(const double *__restrict
     }
 }
 
+// Measurement only: the same waves read the same units with the same rolling
+// 8-row window, but do nothing with the data except fold it into a checksum --
+// the practical HBM read ceiling for this access pattern on this box.
+template <bool NT>
+__global__ __launch_bounds__(256, 4) void stream_read_kernel(const float4 *__restrict__ units,
+                                                             const int2 *__restrict__ wave_range,
+                                                             int stride,
+                                                             float *__restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int ua = wave_range[w].x, ub = wave_range[w].y;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ua < ub) {
+        float4 d[kRowsPerUnit];
+        const float4 *first = units + (int64_t)ua * (kRowsPerUnit * 64) + lane;
+#pragma unroll
+        for (int r = 0; r < kRowsPerUnit; ++r) d[r] = stream_load<NT>(first + r * 64);
+        for (int u = ua; u < ub; u += stride) {
+            const int un = u + stride < ub ? u + stride : u;
+            const float4 *next = units + (int64_t)un * (kRowsPerUnit * 64) + lane;
+#pragma unroll
+            for (int r = 0; r < kRowsPerUnit; ++r) {
+                acc.x += d[r].x; acc.y += d[r].y; acc.z += d[r].z; acc.w += d[r].w;
+                d[r] = stream_load<NT>(next + r * 64);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[w] = acc.x;  // keep the loads alive
+}
+
 template <typename T>
 __global__ void f64_to_T_kernel(const double *__restrict__ in, T *__restrict__ out, int64_t n) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -632,7 +706,9 @@ struct bb_solver {
     void *d_units = nullptr, *d_X = nullptr, *d_part = nullptr, *d_exch = nullptr;
     bool own_exch = false;
     int2 *d_udesc = nullptr;
-    int64_t *d_wave_begin = nullptr;
+    int2 *d_wave_range = nullptr;
+    int stride = 1;
+    bool nontemporal = true;
     int32_t *d_wave_slot = nullptr;
     double *d_stresspart = nullptr;
     int64_t *d_blk_ptr = nullptr, *d_blk_chunk = nullptr;    // final stage: one list per block
@@ -671,6 +747,16 @@ int dev_alloc(T **p, int64_t count) {
         if (_rc != BB_OK) return _rc; \
     } while (0)
 
+int interleave() {
+    const char *e = getenv("BB_INTERLEAVE");
+    int v = e ? atoi(e) : 1;
+    if (v < 1) v = 1;
+    if (v > 1024) v = 1024;
+    int p2 = 1;
+    while (p2 * 2 <= v) p2 *= 2;
+    return p2;
+}
+
 int waves_per_cu() {
     const char *e = getenv("BB_WAVES_PER_CU");
     int v = e ? atoi(e) : 16;
@@ -702,20 +788,35 @@ int build_indices(bb_solver *s) {
     nw = bb::round_up(nw, 4);
     s->n_waves = (int)nw;
 
-    std::vector<int64_t> wave_begin(nw + 1);
+    // Groups of `stride` waves share a contiguous chunk and interleave its units.
+    if (s->n_local >= ((int64_t)1 << 31))
+        return bb::fail(BB_ERR_INVALID, "bb_solver_create: more than 2^31 units on one rank");
+    int64_t stride = interleave();
+    while (stride > 1 && nw % stride) stride >>= 1;
+    s->stride = (int)stride;
+    {
+        // non-temporal matrix loads are the default (measured: +2.5 % on the
+        // kernel, +9 % on a pure read sweep); BB_NT=0 turns them off
+        const char *e = getenv("BB_NT");
+        s->nontemporal = !(e && atoi(e) == 0);
+    }
+    const int64_t groups = nw / stride;
+    std::vector<int2> wave_range(nw);
     std::vector<int32_t> wave_slot(nw);
-    // waves beyond n_local (padding to a multiple of 4) get empty chunks
-    const int64_t active = std::max<int64_t>(1, std::min<int64_t>(want, s->n_local));
-    for (int64_t w = 0; w <= nw; ++w) {
-        const int64_t ww = std::min(w, active);
-        wave_begin[w] = (int64_t)((__int128)s->n_local * ww / active);
+    for (int64_t g = 0; g < groups; ++g) {
+        const int64_t ga = (int64_t)((__int128)s->n_local * g / groups);
+        const int64_t gb = (int64_t)((__int128)s->n_local * (g + 1) / groups);
+        for (int64_t k = 0; k < stride; ++k) {
+            const int64_t w = g * stride + k;
+            wave_range[w] = make_int2((int)std::min(ga + k, gb), (int)gb);
+        }
     }
     // column-partial slots: one per (wave, strip) intersection, in wave order
     std::vector<int32_t> slot_strip;
     for (int64_t w = 0; w < nw; ++w) {
         wave_slot[w] = (int32_t)slot_strip.size();
         int cur = -1;
-        for (int64_t ul = wave_begin[w]; ul < wave_begin[w + 1]; ++ul) {
+        for (int64_t ul = wave_range[w].x; ul < wave_range[w].y; ul += stride) {
             const int J = s->udesc[ul].y / (int)vw;
             if (J != cur) {
                 slot_strip.push_back(J);
@@ -770,7 +871,7 @@ int build_indices(bb_solver *s) {
     BB_TRY(dev_alloc((char **)&s->d_X, s->L.n_pad * 3 * es));
     BB_TRY(dev_alloc((char **)&s->d_part, part_total * es));
     BB_TRY(dev_alloc(&s->d_udesc, (int64_t)s->udesc.size()));
-    BB_TRY(dev_alloc(&s->d_wave_begin, nw + 1));
+    BB_TRY(dev_alloc(&s->d_wave_range, nw));
     BB_TRY(dev_alloc(&s->d_wave_slot, nw));
     BB_TRY(dev_alloc(&s->d_stresspart, nw));
     BB_TRY(dev_alloc(&s->d_blk_ptr, nb + 1));
@@ -787,7 +888,7 @@ int build_indices(bb_solver *s) {
     hipStream_t st = s->stream;
     BB_HIP_CHECK(hipMemcpyAsync(s->d_udesc, s->udesc.data(), s->udesc.size() * sizeof(int2),
                                 hipMemcpyHostToDevice, st));
-    BB_HIP_CHECK(hipMemcpyAsync(s->d_wave_begin, wave_begin.data(), (nw + 1) * sizeof(int64_t),
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_wave_range, wave_range.data(), nw * sizeof(int2),
                                 hipMemcpyHostToDevice, st));
     BB_HIP_CHECK(hipMemcpyAsync(s->d_wave_slot, wave_slot.data(), nw * sizeof(int32_t),
                                 hipMemcpyHostToDevice, st));
@@ -810,17 +911,21 @@ int build_indices(bb_solver *s) {
 
 template <typename T>
 int launch_grad_t(bb_solver *s) {
-    GradParams<T> p;
-    p.units = (const T *)s->d_units;
-    p.X = (const T *)s->d_X;
-    p.udesc = s->d_udesc;
-    p.wave_begin = s->d_wave_begin;
-    p.wave_slot = s->d_wave_slot;
-    p.rowpart = (T *)s->d_part;
-    p.colpart = (T *)s->d_part + s->rowpart_elems;
-    p.stresspart = s->d_stresspart;
-    p.row_shift = s->u_begin - s->t_first * s->L.units_per_tile;
-    hipLaunchKernelGGL(stress_grad_kernel<T>, dim3(s->n_waves / 4), dim3(256), 0, s->stream, p);
+    const T *units = (const T *)s->d_units;
+    const T *X = (const T *)s->d_X;
+    // row partials are indexed by local unit; the buffer starts at the rank's first tile
+    T *rowpart = (T *)s->d_part +
+                 (s->u_begin - s->t_first * s->L.units_per_tile) * (3 * kRowsPerUnit);
+    T *colpart = (T *)s->d_part + s->rowpart_elems;
+    const dim3 grid(s->n_waves / 4), block(256);
+    if (s->nontemporal)
+        hipLaunchKernelGGL((stress_grad_kernel<T, true>), grid, block, 0, s->stream, units, X,
+                           s->d_udesc, s->d_wave_range, s->d_wave_slot, rowpart, colpart,
+                           s->d_stresspart, s->stride);
+    else
+        hipLaunchKernelGGL((stress_grad_kernel<T, false>), grid, block, 0, s->stream, units, X,
+                           s->d_udesc, s->d_wave_range, s->d_wave_slot, rowpart, colpart,
+                           s->d_stresspart, s->stride);
     BB_HIP_CHECK(hipGetLastError());
     return BB_OK;
 }
@@ -1002,7 +1107,7 @@ int bb_solver_destroy(bb_solver *s) {
     hipFree(s->d_part);
     if (s->own_exch) hipFree(s->d_exch);
     hipFree(s->d_udesc);
-    hipFree(s->d_wave_begin);
+    hipFree(s->d_wave_range);
     hipFree(s->d_wave_slot);
     hipFree(s->d_stresspart);
     hipFree(s->d_blk_ptr);
@@ -1300,6 +1405,39 @@ int bb_solver_get_timing(bb_solver *s, double *grad_ms_avg, double *reduce_ms_av
     if (grad_ms_avg) *grad_ms_avg = n ? g / n : 0.0;
     if (reduce_ms_avg) *reduce_ms_avg = n ? r / n : 0.0;
     if (launches) *launches = (int64_t)n;
+    return BB_OK;
+}
+
+int bb_solver_measure_stream_read(bb_solver *s, int launches, double *ms_avg) {
+    BB_REQUIRE(s != nullptr && ms_avg != nullptr, "bb_solver_measure_stream_read: NULL argument");
+    BB_REQUIRE(launches >= 1 && launches <= 1000, "bb_solver_measure_stream_read: bad launches");
+    if (!s->have_wish)
+        return bb::fail(BB_ERR_STATE, "bb_solver_measure_stream_read: no wish distances set");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    hipEvent_t e0, e1;
+    BB_HIP_CHECK(hipEventCreate(&e0));
+    BB_HIP_CHECK(hipEventCreate(&e1));
+    auto launch = [&]() {
+        if (s->nontemporal)
+            hipLaunchKernelGGL((stream_read_kernel<true>), dim3(s->n_waves / 4), dim3(256), 0,
+                               s->stream, (const float4 *)s->d_units, s->d_wave_range, s->stride,
+                               (float *)s->d_f64_tmp);
+        else
+            hipLaunchKernelGGL((stream_read_kernel<false>), dim3(s->n_waves / 4), dim3(256), 0,
+                               s->stream, (const float4 *)s->d_units, s->d_wave_range, s->stride,
+                               (float *)s->d_f64_tmp);
+    };
+    launch();  // warm-up
+    BB_HIP_CHECK(hipEventRecord(e0, s->stream));
+    for (int k = 0; k < launches; ++k) launch();
+    BB_HIP_CHECK(hipEventRecord(e1, s->stream));
+    BB_HIP_CHECK(hipGetLastError());
+    BB_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    BB_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *ms_avg = ms / launches;
     return BB_OK;
 }
 

@@ -172,6 +172,13 @@ class HipEngine(object):
         _lib.check(self._lib.bb_solver_get_timing(self._h, g, r, n), "bb_solver_get_timing")
         return {"grad_ms": float(g.value), "reduce_ms": float(r.value), "launches": int(n.value)}
 
+    def stream_read_ms(self, launches=10):
+        """Average ms of a read-only sweep over the resident units (measurement aid)."""
+        ms = _lib.c_dbl()
+        _lib.check(self._lib.bb_solver_measure_stream_read(self._h, int(launches), ms),
+                   "bb_solver_measure_stream_read")
+        return float(ms.value)
+
     def traffic(self):
         b, p = _lib.c_i64(), _lib.c_i64()
         _lib.check(self._lib.bb_solver_traffic(self._h, b, p), "bb_solver_traffic")

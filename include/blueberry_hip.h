@@ -171,6 +171,11 @@ BB_API int bb_solver_sync(bb_solver *s);
 BB_API int bb_solver_set_timing(bb_solver *s, int enabled);
 BB_API int bb_solver_get_timing(bb_solver *s, double *grad_ms_avg, double *reduce_ms_avg,
                                 int64_t *launches);
+/* Measurement aid: average duration of a kernel that only READS this rank's
+ * resident units (same grid, same per-wave chunks, same 8-row window, no
+ * arithmetic) -- the practical HBM ceiling for the access pattern, to put
+ * beside the spec peak in the roofline. */
+BB_API int bb_solver_measure_stream_read(bb_solver *s, int launches, double *ms_avg);
 /* Bytes of wish-distance data the stress+gradient kernel streams per launch on
  * this rank (resident units * unit bytes), and pairs evaluated. */
 BB_API int bb_solver_traffic(const bb_solver *s, int64_t *unit_bytes, int64_t *pairs_dense);
