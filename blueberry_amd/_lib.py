@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libblueberry_hip.so")
+# BB_LIB: load another build of the same library (kernel-tuning experiments only)
+LIB_PATH = os.environ.get("BB_LIB") or os.path.join(_HERE, "libblueberry_hip.so")
 
 BB_OK, BB_ERR_INVALID, BB_ERR_HIP, BB_ERR_STATE, BB_ERR_NOMEM = 0, 1, 2, 3, 4
 BB_F32, BB_F64 = 0, 1

@@ -53,8 +53,8 @@ int bb_layout_dense_info(int64_t n_bins, int dtype, bb_layout_info *info) {
     info->n_bins = n_bins;
     info->vw = vw;
     info->n_pad = bb::round_up(n_bins, vw);
-    info->rows_per_unit = bb::kRowsPerUnit;
-    info->units_per_tile = vw / bb::kRowsPerUnit;
+    info->rows_per_unit = bb::rows_per_unit(dtype);
+    info->units_per_tile = vw / info->rows_per_unit;
     info->n_blocks = info->n_pad / vw;
     info->n_tiles = info->n_blocks * (info->n_blocks + 1) / 2;
     info->n_units = info->n_tiles * info->units_per_tile;

@@ -28,13 +28,13 @@ int fail(int code, const std::string &msg);
     } while (0)
 
 // ---- layout constants (docs/SPEC.md 3) -----------------------------------
-// A wave row is 64 lanes x 16 B = 1 KiB: 256 fp32 or 128 fp64 columns.
-constexpr int kRowsPerUnit = 8;
-constexpr int kWaveRowBytes = 1024;
-constexpr int kUnitBytes = kRowsPerUnit * kWaveRowBytes;  // 8 KiB
+// A unit is always 8 KiB = 8 wave-loads of 64 lanes x 16 B.
+//   fp32: 4 matrix rows x 512 columns (2 loads per row); fp64: 8 rows x 128 columns.
+constexpr int kUnitBytes = 8192;
 
 inline int64_t elem_size(int dtype) { return dtype == BB_F64 ? 8 : 4; }
-inline int64_t tile_width(int dtype) { return kWaveRowBytes / elem_size(dtype); }
+inline int64_t tile_width(int dtype) { return dtype == BB_F64 ? 128 : 512; }
+inline int64_t rows_per_unit(int dtype) { return dtype == BB_F64 ? 8 : 4; }
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 // Select the device, failing loudly when there is none.

@@ -5,14 +5,15 @@
 // Specification: docs/SPEC.md (build-authored; the reference has no solver,
 // SURVEY.md section 0).  Data layout and kernel design: DESIGN.md 3-4.
 //
-// Layout recap (SPEC 3).  The matrix is cut into vw x vw tiles (vw = 1 KiB of
-// elements: 256 fp32 / 128 fp64), upper-triangular tiles only, ordered
-// column-strip major (J, then I).  A tile is vw/8 "units"; a unit is 8 matrix
-// rows x vw columns = 8 KiB, row-major, so one wave reads one matrix row of a
-// unit with one 16-B-per-lane load and lane l always owns the same VPL columns
-// of the strip.  That makes the column side of the symmetric update
-// register-resident for a whole strip sweep (no cross-lane traffic), and only
-// the row side needs one DPP wave reduction per matrix row.
+// Layout recap (SPEC 3).  The matrix is cut into vw x vw tiles (vw = 512 fp32 /
+// 128 fp64 columns), upper-triangular tiles only, ordered column-strip major
+// (J, then I).  A tile is vw/rpu "units"; a unit is rpu matrix rows x vw
+// columns = 8 KiB, row-major (fp32: 4 rows of 2 KiB; fp64: 8 rows of 1 KiB).
+// One wave reads a matrix row of a unit with LPR 16-B-per-lane loads and lane
+// l always owns the same LPR*VPL columns of the strip.  That makes the column
+// side of the symmetric update register-resident for a whole strip sweep (no
+// cross-lane traffic), and only the row side needs one DPP wave reduction per
+// matrix row -- amortised over 8 pairs per lane in fp32.
 #include <math.h>
 
 #include <algorithm>
@@ -23,7 +24,6 @@
 
 namespace {
 
-using bb::kRowsPerUnit;
 
 // --------------------------------------------------------------------------
 // type traits
@@ -34,14 +34,18 @@ template <>
 struct Traits<float> {
     using Vec = float4;
     static constexpr int VPL = 4;  // elements per lane per 16-B load
-    static constexpr int VW = 256;
+    static constexpr int LPR = 2;  // 16-B loads per lane per matrix row
+    static constexpr int VW = 512; // columns of a strip = 64 * VPL * LPR
+    static constexpr int RPU = 4;  // matrix rows per 8-KiB unit
     static __device__ __forceinline__ float eps2() { return 1e-30f; }
 };
 template <>
 struct Traits<double> {
     using Vec = double2;
     static constexpr int VPL = 2;
+    static constexpr int LPR = 1;
     static constexpr int VW = 128;
+    static constexpr int RPU = 8;
     static __device__ __forceinline__ double eps2() { return 1e-300; }
 };
 
@@ -165,8 +169,7 @@ __device__ __forceinline__ void pair_step(const typename Traits<T>::Vec &drow, T
                                           T (&gc)[Traits<T>::VPL][3], T &gx, T &gy, T &gz, T &s) {
     const T delta = elem<C>(drow);
     const T dx = xi - xj[C][0], dy = yi - xj[C][1], dz = zi - xj[C][2];
-    T d2 = fma(dx, dx, fma(dy, dy, dz * dz));
-    d2 = d2 < Traits<T>::eps2() ? Traits<T>::eps2() : d2;
+    const T d2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, Traits<T>::eps2())));  // SPEC 2.2
     T rinv, dist;
     if constexpr (sizeof(T) == 4) {
         rinv = __builtin_amdgcn_rsqf(d2);
@@ -210,15 +213,16 @@ __device__ __forceinline__ double2 stream_load(const double2 *p) {
 // then d[r] is immediately refilled with row r of the NEXT unit, so 8 KiB per
 // wave stay in flight with a single 8-row register buffer.
 template <typename T, bool NT>
-__device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[kRowsPerUnit], T xrow,
+__device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[Traits<T>::RPU], T xrow,
                                              const typename Traits<T>::Vec *__restrict__ next,
                                              const T (&xj)[Traits<T>::VPL][3],
                                              T (&gc)[Traits<T>::VPL][3], double &stress,
                                              __amdgpu_buffer_rsrc_t row_rsrc, unsigned row_voff) {
     constexpr int VPL = Traits<T>::VPL;
+    static_assert(Traits<T>::LPR == 1, "generic path: one load per matrix row");
     T s = T(0);
 #pragma unroll
-    for (int r = 0; r < kRowsPerUnit; ++r) {
+    for (int r = 0; r < Traits<T>::RPU; ++r) {
         const T xi = lane_value(xrow, 3 * r), yi = lane_value(xrow, 3 * r + 1),
                 zi = lane_value(xrow, 3 * r + 2);
         T gx = T(0), gy = T(0), gz = T(0);
@@ -240,95 +244,149 @@ __device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[kRowsP
 }
 
 // ---- fp32: the same unit with explicit 2-wide packed math (v_pk_*_f32) -------
-// Pairs (0,1) and (2,3) of a lane's four columns share every instruction that
-// has a packed form; column-side state is kept as [component][pair] so that
-// the two pairs sit in adjacent registers.
+// A lane owns 8 columns of the 512-wide strip: load k (k = 0,1) brings columns
+// k*256 + 4*lane .. +3, and within a load the pairs {0,1} and {2,3} share every
+// instruction that has a packed form.  Column-side state is [load][half]
+// [component] so that the two pairs of a half sit in adjacent registers.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct StripF32 {
-    f32x2 x[2][3];  // [half][component]: coordinates of columns {0,1} and {2,3}
-    f32x2 g[2][3];  // column-side gradient accumulators, same shape
+    f32x2 x[2][2][3];  // coordinates of this lane's columns
+    f32x2 g[2][2][3];  // column-side gradient accumulators, same shape
 };
 
-template <int H>
+// w = 1 where delta > 0, else 0, for both halves in ONE instruction:
+// clamp(delta * 2^100) saturates any delta >= 2^-100 to 1 and leaves 0 at 0
+// (delta is never negative or NaN: the pack kernels store 0 for "no
+// constraint" and flush anything below 1e-30).  Replaces 2 v_cmp + 2 v_cndmask.
+__device__ __forceinline__ f32x2 weight01(f32x2 delta) {
+    f32x2 w;
+    const f32x2 big = {0x1p100f, 0x1p100f};
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(w) : "v"(delta), "v"(big));
+    return w;
+}
+
+template <int K, int H, bool FIRST>
 __device__ __forceinline__ void pair_step2(f32x2 delta, f32x2 xi, f32x2 yi, f32x2 zi, StripF32 &st,
                                            f32x2 &rx, f32x2 &ry, f32x2 &rz, f32x2 &s2) {
-    const f32x2 dx = xi - st.x[H][0], dy = yi - st.x[H][1], dz = zi - st.x[H][2];
-    f32x2 d2 = dx * dx + dy * dy + dz * dz;
-    d2.x = fmaxf(d2.x, 1e-30f);
-    d2.y = fmaxf(d2.y, 1e-30f);
+    const f32x2 eps2 = {1e-30f, 1e-30f};
+    const f32x2 dx = xi - st.x[K][H][0], dy = yi - st.x[K][H][1], dz = zi - st.x[K][H][2];
+    const f32x2 d2 = dx * dx + (dy * dy + (dz * dz + eps2));  // SPEC 2.2: |d|^2 + eps^2
     f32x2 rinv;
+#ifdef BB_ABL_NORSQ  // timing experiment: wrong results
+    rinv = d2 * eps2;
+#else
     rinv.x = __builtin_amdgcn_rsqf(d2.x);
     rinv.y = __builtin_amdgcn_rsqf(d2.y);
-    f32x2 res = d2 * rinv - delta;  // dist - delta
-    res.x = delta.x > 0.f ? res.x : 0.f;
-    res.y = delta.y > 0.f ? res.y : 0.f;
+#endif
+#ifdef BB_ABL_NOMASK
+    const f32x2 res = (d2 * rinv - delta);
+#else
+    const f32x2 res = (d2 * rinv - delta) * weight01(delta);  // (dist - delta) or 0
+#endif
     s2 += res * res;
     const f32x2 coef = res * rinv;
-    if constexpr (H == 0) {
+    if constexpr (FIRST) {
         rx = coef * dx; ry = coef * dy; rz = coef * dz;
     } else {
         rx += coef * dx; ry += coef * dy; rz += coef * dz;
     }
-    st.g[H][0] -= coef * dx;
-    st.g[H][1] -= coef * dy;
-    st.g[H][2] -= coef * dz;
+#ifndef BB_ABL_NOCOL
+    st.g[K][H][0] -= coef * dx;
+    st.g[K][H][1] -= coef * dy;
+    st.g[K][H][2] -= coef * dz;
+#endif
 }
 
+// d[] holds the unit's 8 wave-loads in row order: d[2*r + k] = row r, load k.
 template <bool NT>
-__device__ __forceinline__ void process_unit_f32(float4 (&d)[kRowsPerUnit], float xrow,
+__device__ __forceinline__ void process_unit_f32(float4 (&d)[8], float xrow,
                                                  const float4 *__restrict__ next, StripF32 &st,
                                                  double &stress, __amdgpu_buffer_rsrc_t row_rsrc,
                                                  unsigned row_voff) {
     f32x2 s2 = {0.f, 0.f};
+    // The 12 row sums of the unit are collected into lanes 48..59 of one register
+    // (after the reduction every lane >= 48 holds the wave total) and leave with
+    // ONE 48-byte store per unit: a 12-byte store per row costs as much VMEM issue
+    // as a 1-KiB load and measured 5.6 % of the kernel.
+    const int slot = (int)(threadIdx.x & 63) - 48;  // value index this lane keeps, if 0..11
+    const int comp = slot - 3 * (slot / 3);     // 0,1,2 = x,y,z
+    float keep = 0.f;
 #pragma unroll
-    for (int r = 0; r < kRowsPerUnit; ++r) {
+    for (int r = 0; r < 4; ++r) {
         const float xs = lane_value(xrow, 3 * r), ys = lane_value(xrow, 3 * r + 1),
                     zs = lane_value(xrow, 3 * r + 2);
         const f32x2 xi = {xs, xs}, yi = {ys, ys}, zi = {zs, zs};
-        f32x2 rx, ry, rz;
-        pair_step2<0>(f32x2{d[r].x, d[r].y}, xi, yi, zi, st, rx, ry, rz, s2);
-        pair_step2<1>(f32x2{d[r].z, d[r].w}, xi, yi, zi, st, rx, ry, rz, s2);
-        d[r] = stream_load<NT>(next + r * 64);
+        f32x2 rx, ry, rz, qx, qy, qz;  // row-side sums of load 0 / load 1
+        pair_step2<0, 0, true>(f32x2{d[2 * r].x, d[2 * r].y}, xi, yi, zi, st, rx, ry, rz, s2);
+        pair_step2<0, 1, false>(f32x2{d[2 * r].z, d[2 * r].w}, xi, yi, zi, st, rx, ry, rz, s2);
+        d[2 * r] = stream_load<NT>(next + (2 * r) * 64);
+        // three scheduling regions per row (load 0 | load 1 | reduce+store): inside a
+        // region the two halves interleave, which hides the 1-wait-state hazard
+        // between dependent v_pk_* ops that costs an s_nop when they run back to back
+        __builtin_amdgcn_sched_barrier(0);
+        pair_step2<1, 0, true>(f32x2{d[2 * r + 1].x, d[2 * r + 1].y}, xi, yi, zi, st, qx, qy, qz, s2);
+        pair_step2<1, 1, false>(f32x2{d[2 * r + 1].z, d[2 * r + 1].w}, xi, yi, zi, st, qx, qy, qz, s2);
+        d[2 * r + 1] = stream_load<NT>(next + (2 * r + 1) * 64);
+        __builtin_amdgcn_sched_barrier(0);
+        rx += qx; ry += qy; rz += qz;
         float gx = rx.x + rx.y, gy = ry.x + ry.y, gz = rz.x + rz.y;
+#ifndef BB_ABL_NODPP
         wave_sum_hi3(gx, gy, gz);
-        store_row3(row_rsrc, row_voff + r * 12u, gx, gy, gz);
+#endif
+        const float mine = comp == 0 ? gx : (comp == 1 ? gy : gz);
+        keep = (slot >= 3 * r && slot < 3 * r + 3) ? mine : keep;
         __builtin_amdgcn_sched_barrier(0);
     }
+#ifndef BB_ABL_NOSTORE
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(keep), row_rsrc, row_voff, 0, 0);
+#else
+    asm volatile("" ::"v"(keep));
+#endif
     stress += (double)(s2.x + s2.y);
 }
 
 __device__ __forceinline__ void load_strip_f32(StripF32 &st, const float *__restrict__ X, int j0,
                                                int lane) {
-    const float4 *p = reinterpret_cast<const float4 *>(X + ((int64_t)j0 + (int64_t)lane * 4) * 3);
-    const float4 a = p[0], b = p[1], c = p[2];  // x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3
-    st.x[0][0] = f32x2{a.x, a.w}; st.x[0][1] = f32x2{a.y, b.x}; st.x[0][2] = f32x2{a.z, b.y};
-    st.x[1][0] = f32x2{b.z, c.y}; st.x[1][1] = f32x2{b.w, c.z}; st.x[1][2] = f32x2{c.x, c.w};
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int k = 0; k < 2; ++k) {
+        const float4 *p = reinterpret_cast<const float4 *>(
+            X + ((int64_t)j0 + k * 256 + (int64_t)lane * 4) * 3);
+        const float4 a = p[0], b = p[1], c = p[2];  // x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3
+        st.x[k][0][0] = f32x2{a.x, a.w}; st.x[k][0][1] = f32x2{a.y, b.x};
+        st.x[k][0][2] = f32x2{a.z, b.y};
+        st.x[k][1][0] = f32x2{b.z, c.y}; st.x[k][1][1] = f32x2{b.w, c.z};
+        st.x[k][1][2] = f32x2{c.x, c.w};
 #pragma unroll
-        for (int c3 = 0; c3 < 3; ++c3) st.g[h][c3] = f32x2{0.f, 0.f};
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) st.g[k][h][c3] = f32x2{0.f, 0.f};
+    }
 }
 
 __device__ __forceinline__ void store_strip_f32(const StripF32 &st, float *__restrict__ slot,
                                                 int lane) {
-    float4 *p = reinterpret_cast<float4 *>(slot + (int64_t)lane * 12);
-    p[0] = make_float4(st.g[0][0].x, st.g[0][1].x, st.g[0][2].x, st.g[0][0].y);
-    p[1] = make_float4(st.g[0][1].y, st.g[0][2].y, st.g[1][0].x, st.g[1][1].x);
-    p[2] = make_float4(st.g[1][2].x, st.g[1][0].y, st.g[1][1].y, st.g[1][2].y);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float4 *p = reinterpret_cast<float4 *>(slot + (k * 256 + (int64_t)lane * 4) * 3);
+        const auto &g = st.g[k];
+        p[0] = make_float4(g[0][0].x, g[0][1].x, g[0][2].x, g[0][0].y);
+        p[1] = make_float4(g[0][1].y, g[0][2].y, g[1][0].x, g[1][1].x);
+        p[2] = make_float4(g[1][2].x, g[1][0].y, g[1][1].y, g[1][2].y);
+    }
 }
 
 template <typename T>
 __device__ __forceinline__ const typename Traits<T>::Vec *unit_ptr(const T *__restrict__ units,
                                                                    int64_t ul, int lane) {
     using Vec = typename Traits<T>::Vec;
-    return reinterpret_cast<const Vec *>(units) + ul * (kRowsPerUnit * 64) + lane;
+    return reinterpret_cast<const Vec *>(units) + ul * 512 + lane;  // 8 KiB = 512 x 16 B
 }
 
-// coordinates of a unit's 8 rows: 24 consecutive elements, one per lane
+// coordinates of a unit's rows: 3*RPU consecutive elements, one per lane
 template <typename T>
 __device__ __forceinline__ T load_xrow(const T *__restrict__ X, int i0, int lane) {
-    return X[(int64_t)i0 * 3 + (lane < 3 * kRowsPerUnit ? lane : 0)];
+    return X[(int64_t)i0 * 3 + (lane < 3 * Traits<T>::RPU ? lane : 0)];
 }
 
 template <typename T>
@@ -375,12 +433,12 @@ __device__ __forceinline__ void store_strip(const T (&gc)[Traits<T>::VPL][3],
 // Arguments are separate __restrict__ pointers (not a struct) so that the
 // read-only index arrays are provably unclobbered and load through the scalar
 // cache.  Unit indices are 32-bit (a rank holds < 2^31 units = 16 TiB).
-//   units      this rank's units, 8*VW elements each
+//   units      this rank's units, 8 KiB (RPU rows x VW columns) each
 //   X          (n_pad, 3) coordinates
 //   udesc      per local unit {i0, j0}
 //   wave_range per wave {first, end} local unit indices
 //   wave_slot  first column-partial slot of each wave
-//   rowpart    24 elements per unit, base shifted to the rank's first tile
+//   rowpart    3*RPU elements per unit, base shifted to the rank's first tile
 //   colpart    3*VW elements per slot
 //   stresspart one double per wave
 template <typename T, bool NT>
@@ -400,7 +458,7 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
 
     if (ua < ub) {
         int slot = wave_slot[w];
-        Vec d[kRowsPerUnit];
+        Vec d[8];  // the unit's 8 wave-loads (8 KiB), in memory order
         // column-strip state: coordinates + gradient accumulators of this lane's columns
         struct Generic { T xj[VPL][3], gc[VPL][3]; };
         using Strip = typename std::conditional<sizeof(T) == 4, StripF32, Generic>::type;
@@ -428,12 +486,12 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
         {
             const Vec *first = unit_ptr<T>(units, ua, lane);
 #pragma unroll
-            for (int r = 0; r < kRowsPerUnit; ++r) d[r] = stream_load<NT>(first + r * 64);
+            for (int r = 0; r < 8; ++r) d[r] = stream_load<NT>(first + r * 64);
         }
-        // this wave's row partials: 24 elements per unit of its group's chunk
-        constexpr unsigned kRowBytes = 3 * kRowsPerUnit * sizeof(T);
+        // this wave's row partials: 3*RPU elements per unit of its group's chunk
+        constexpr unsigned kRowBytes = 3 * Traits<T>::RPU * sizeof(T);
         const __amdgpu_buffer_rsrc_t row_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            rowpart + (int64_t)ua * (3 * kRowsPerUnit), 0, (int)((unsigned)(ub - ua) * kRowBytes),
+            rowpart + (int64_t)ua * (3 * Traits<T>::RPU), 0, (int)((unsigned)(ub - ua) * kRowBytes),
             0x00020000);
 
         auto unit_step = [&](int u) __attribute__((always_inline)) {
@@ -441,7 +499,13 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
             const int un = u + stride < ub ? u + stride : u;
             const T xrn = load_xrow<T>(X, dn.x, lane);
             const int2 dnn = udesc[un + stride < ub ? un + stride : un];
-            const unsigned row_voff = lane == 63 ? (unsigned)(u - ua) * kRowBytes : kDropOffset;
+            unsigned row_voff;
+            if constexpr (sizeof(T) == 4)   // fp32: lanes 48..59 store one of the 12 sums each
+                row_voff = (lane >= 48 && lane < 60)
+                               ? (unsigned)(u - ua) * kRowBytes + (unsigned)(lane - 48) * 4u
+                               : kDropOffset;
+            else                            // fp64: lane 63 stores each row's three sums
+                row_voff = lane == 63 ? (unsigned)(u - ua) * kRowBytes : kDropOffset;
             if constexpr (sizeof(T) == 4)
                 process_unit_f32<NT>(d, xr, unit_ptr<T>(units, un, lane), st, stress, row_rsrc,
                                      row_voff);
@@ -605,8 +669,9 @@ __global__ __launch_bounds__(256) void convert_units_kernel(
     constexpr int VW = Traits<T>::VW;
     const int64_t ul = ul0 + blockIdx.x;
     const int2 dsc = udesc[ul];
-    T *out = units_out + ul * (kRowsPerUnit * VW);
-    for (int e = threadIdx.x; e < kRowsPerUnit * VW; e += 256) {
+    constexpr int RPU = Traits<T>::RPU;
+    T *out = units_out + ul * (RPU * VW);
+    for (int e = threadIdx.x; e < RPU * VW; e += 256) {
         const int r = e / VW, c = e % VW;
         const int64_t i = (int64_t)dsc.x + r, j = (int64_t)dsc.y + c;
         double v = 0.0;
@@ -618,6 +683,9 @@ __global__ __launch_bounds__(256) void convert_units_kernel(
             else if (kind == BB_KIND_COUNTS)
                 v = pow(v, neg_inv_alpha);
         }
+        // fp32: the kernel's 0/1 weight needs delta >= 2^-100; anything that small
+        // is below the distance clamp eps = 1e-15 anyway and is stored as "none"
+        if (sizeof(T) == 4 && v < 1e-30) v = 0.0;
         out[e] = (T)v;
     }
 }
@@ -631,8 +699,9 @@ __global__ __launch_bounds__(256) void gen_units_kernel(const double *__restrict
     constexpr int VW = Traits<T>::VW;
     const int64_t ul = blockIdx.x;
     const int2 dsc = udesc[ul];
-    T *out = units_out + ul * (kRowsPerUnit * VW);
-    for (int e = threadIdx.x; e < kRowsPerUnit * VW; e += 256) {
+    constexpr int RPU = Traits<T>::RPU;
+    T *out = units_out + ul * (RPU * VW);
+    for (int e = threadIdx.x; e < RPU * VW; e += 256) {
         const int r = e / VW, c = e % VW;
         const int64_t i = (int64_t)dsc.x + r, j = (int64_t)dsc.y + c;
         double v = 0.0;
@@ -641,6 +710,7 @@ __global__ __launch_bounds__(256) void gen_units_kernel(const double *__restrict
                          dz = xs[3 * i + 2] - xs[3 * j + 2];
             v = sqrt(dx * dx + dy * dy + dz * dz);
         }
+        if (sizeof(T) == 4 && v < 1e-30) v = 0.0;
         out[e] = (T)v;
     }
 }
@@ -658,15 +728,15 @@ __global__ __launch_bounds__(256, 4) void stream_read_kernel(const float4 *__res
     const int ua = wave_range[w].x, ub = wave_range[w].y;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ua < ub) {
-        float4 d[kRowsPerUnit];
-        const float4 *first = units + (int64_t)ua * (kRowsPerUnit * 64) + lane;
+        float4 d[8];
+        const float4 *first = units + (int64_t)ua * 512 + lane;
 #pragma unroll
-        for (int r = 0; r < kRowsPerUnit; ++r) d[r] = stream_load<NT>(first + r * 64);
+        for (int r = 0; r < 8; ++r) d[r] = stream_load<NT>(first + r * 64);
         for (int u = ua; u < ub; u += stride) {
             const int un = u + stride < ub ? u + stride : u;
-            const float4 *next = units + (int64_t)un * (kRowsPerUnit * 64) + lane;
+            const float4 *next = units + (int64_t)un * 512 + lane;
 #pragma unroll
-            for (int r = 0; r < kRowsPerUnit; ++r) {
+            for (int r = 0; r < 8; ++r) {
                 acc.x += d[r].x; acc.y += d[r].y; acc.z += d[r].z; acc.w += d[r].w;
                 d[r] = stream_load<NT>(next + r * 64);
                 __builtin_amdgcn_sched_barrier(0);
@@ -777,7 +847,7 @@ int build_indices(bb_solver *s) {
     s->udesc.resize((size_t)std::max<int64_t>(s->n_local, 1));
     for (int64_t ul = 0; ul < s->n_local; ++ul) {
         const int64_t u = s->u_begin + ul, t = u / upt, sub = u % upt;
-        s->udesc[ul] = make_int2((int)(s->tile_I[t] * vw + sub * kRowsPerUnit),
+        s->udesc[ul] = make_int2((int)(s->tile_I[t] * vw + sub * s->L.rows_per_unit),
                                  (int)(s->tile_J[t] * vw));
     }
 
@@ -915,7 +985,7 @@ int launch_grad_t(bb_solver *s) {
     const T *X = (const T *)s->d_X;
     // row partials are indexed by local unit; the buffer starts at the rank's first tile
     T *rowpart = (T *)s->d_part +
-                 (s->u_begin - s->t_first * s->L.units_per_tile) * (3 * kRowsPerUnit);
+                 (s->u_begin - s->t_first * s->L.units_per_tile) * (3 * s->L.rows_per_unit);
     T *colpart = (T *)s->d_part + s->rowpart_elems;
     const dim3 grid(s->n_waves / 4), block(256);
     if (s->nontemporal)
@@ -986,7 +1056,7 @@ template <typename T>
 int set_wish_dense_t(bb_solver *s, const double *host, int64_t ld, int kind, double alpha) {
     constexpr int VW = Traits<T>::VW;
     const int64_t upt = s->L.units_per_tile, n = s->L.n_bins;
-    constexpr int64_t kRunTiles = 8;  // tiles staged per copy
+    constexpr int64_t kRunTiles = 4;  // tiles staged per copy
     double *stage = nullptr;
     BB_TRY(dev_alloc(&stage, kRunTiles * VW * VW));
     // Copy, convert and the next copy are all enqueued on the solver's stream,
@@ -999,9 +1069,9 @@ int set_wish_dense_t(bb_solver *s, const double *host, int64_t ld, int kind, dou
         const int64_t i_start = s->udesc[ul].x;
         int64_t ue = ul + 1;
         while (ue < s->n_local && ue - ul < kRunTiles * upt && s->udesc[ue].y == j0 &&
-               s->udesc[ue].x == i_start + (ue - ul) * kRowsPerUnit)
+               s->udesc[ue].x == i_start + (ue - ul) * s->L.rows_per_unit)
             ++ue;
-        const int64_t rows = (ue - ul) * kRowsPerUnit;
+        const int64_t rows = (ue - ul) * s->L.rows_per_unit;
         const int64_t rows_valid =
             std::max<int64_t>(0, std::min<int64_t>(i_start + rows, n) - i_start);
         const int64_t cols_valid =

@@ -77,9 +77,9 @@ BB_API int bb_band_count_rows(const double *regions, int64_t n, int32_t low, int
 typedef struct bb_layout_info {
     int64_t n_bins;         /* N                                              */
     int64_t n_pad;          /* N rounded up to a multiple of vw               */
-    int64_t vw;             /* tile edge = columns per wave row: 1 KiB/sizeof */
-    int64_t rows_per_unit;  /* 8                                              */
-    int64_t units_per_tile; /* vw / 8                                         */
+    int64_t vw;             /* tile edge = strip width: 512 (fp32), 128 (fp64)  */
+    int64_t rows_per_unit;  /* matrix rows per 8-KiB unit: 4 (fp32), 8 (fp64) */
+    int64_t units_per_tile; /* vw / rows_per_unit                             */
     int64_t n_blocks;       /* n_pad / vw                                     */
     int64_t n_tiles;        /* upper-triangular tiles incl. the diagonal      */
     int64_t n_units;        /* n_tiles * units_per_tile                       */

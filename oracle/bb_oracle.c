@@ -166,7 +166,7 @@ BBO_API void bbo_counts_to_wish(const double *counts, long n, long ld_in, double
         }
 }
 
-/* SPEC 2.2: squared distances are clamped below by eps2 before the square
+/* SPEC 2.2: d_ij = sqrt(|x_i - x_j|^2 + eps2): a tiny eps2 under the square
  * root so that coincident points give a finite, zero force. */
 #define BBO_EPS2_F64 1e-300
 #define BBO_EPS2_F32 1e-30
@@ -175,8 +175,7 @@ static inline double pair_term(const double *xi, const double *xj, double delta,
                                double *gi, double *gj)
 {
     double dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
-    double d2 = dx * dx + dy * dy + dz * dz;
-    if (d2 < eps2) d2 = eps2;
+    double d2 = dx * dx + dy * dy + dz * dz + eps2;
     double d = sqrt(d2);
     double r = d - delta;
     double coef = 2.0 * r / d;
@@ -219,8 +218,8 @@ BBO_API void bbo_solve(const double *wish, long n, long ld, double *X, long iter
 /* The pairs owned by a contiguous range of "units" of the device layout
  * (docs/SPEC.md 3; include/blueberry_hip.h bb_layout_*): unit u belongs to
  * tile t = u / units_per_tile with block coordinates (tile_I[t], tile_J[t]),
- * and covers rows  tile_I*vw + (u % units_per_tile)*8 .. +8  and columns
- * tile_J*vw .. +vw, restricted to i < j < n.  Used by the world_size>1 tests
+ * and covers rows  tile_I*vw + (u % units_per_tile)*rpu .. +rpu  (rpu =
+ * vw / units_per_tile) and columns tile_J*vw .. +vw, restricted to i < j < n.  Used by the world_size>1 tests
  * to play one rank's share; summing over a partition of all units must give
  * bbo_stress_grad exactly (up to summation order). */
 BBO_API double bbo_stress_grad_units(const double *wish, long n, long ld, const double *X,
@@ -233,9 +232,10 @@ BBO_API double bbo_stress_grad_units(const double *wish, long n, long ld, const 
     memset(g, 0, sizeof(double) * 3 * (size_t)n);
     for (long u = u_begin; u < u_end; u++) {
         long t = u / units_per_tile, sub = u % units_per_tile;
-        long i0 = (long)tile_I[t] * vw + sub * 8;
+        long rpu = vw / units_per_tile;
+        long i0 = (long)tile_I[t] * vw + sub * rpu;
         long j0 = (long)tile_J[t] * vw;
-        for (long i = i0; i < i0 + 8 && i < n; i++)
+        for (long i = i0; i < i0 + rpu && i < n; i++)
             for (long j = j0; j < j0 + vw && j < n; j++) {
                 if (j <= i) continue;
                 double delta = wish[i * ld + j];
