@@ -1,0 +1,72 @@
+"""Test-only solver engine that plays one rank with the CPU oracle.
+
+It exists so that the multi-rank orchestration in blueberry_amd.solver
+(partition of the packed units over ranks, exchange-buffer layout, one
+all-reduce per iteration, identical update on every rank) can be rehearsed with
+world_size > 1 on a machine without GPUs.  The partition itself comes from the
+PRODUCT library's host-only layout functions (bb_layout_*), so what is tested
+is the real unit ranges.  Never imported by the package."""
+import numpy
+
+from blueberry_amd import _lib
+from tests import _oracle
+
+
+class OracleEngine(object):
+    def __init__(self, n_bins, dtype, rank=0, world=1, device=0, tiles=None):
+        lib = _lib.load()
+        self.n_bins, self.dtype, self.rank, self.world = n_bins, dtype, rank, world
+        code = _lib.BB_F32 if dtype == "float32" else _lib.BB_F64
+        self.info = _lib.LayoutInfo()
+        _lib.check(lib.bb_layout_dense_info(n_bins, code, self.info))
+        self.ti = numpy.zeros(self.info.n_tiles, dtype=numpy.int32)
+        self.tj = numpy.zeros(self.info.n_tiles, dtype=numpy.int32)
+        _lib.check(lib.bb_layout_dense_tiles(n_bins, code, self.ti.ctypes.data_as(_lib.p_i32),
+                                             self.tj.ctypes.data_as(_lib.p_i32),
+                                             self.info.n_tiles))
+        ub, ue = _lib.c_i64(), _lib.c_i64()
+        _lib.check(lib.bb_layout_rank_units(self.info.n_units, rank, world, ub, ue))
+        self.u_begin, self.u_end = int(ub.value), int(ue.value)
+        self.oracle = _oracle.load()
+        self.exch = numpy.zeros(3 * self.info.n_pad + 2)
+        self.hist = []
+
+    def close(self):
+        pass
+
+    def set_wish_dense(self, matrix, kind, alpha):
+        m = numpy.ascontiguousarray(matrix, dtype=numpy.float64)
+        self.w = self.oracle.counts_to_wish(m, alpha) if kind == "counts" else m
+
+    def set_coords(self, x0):
+        self.X = numpy.ascontiguousarray(x0, dtype=numpy.float64).copy()
+        self.hist = []
+
+    def get_coords(self):
+        return self.X.copy()
+
+    def grad(self):
+        s, g = self.oracle.stress_grad_units(self.w, self.X, self.ti, self.tj,
+                                             self.info.units_per_tile, self.info.vw,
+                                             self.u_begin, self.u_end)
+        self.exch[:] = 0
+        self.exch[:3 * self.n_bins] = g.ravel()
+        self.exch[-2] = s
+
+    def read_exchange(self):
+        return self.exch.copy()
+
+    def write_exchange(self, host):
+        self.exch[:] = host
+
+    def apply(self, lr):
+        self.X -= lr * self.exch[:3 * self.n_bins].reshape(self.n_bins, 3)
+        self.hist.append(self.exch[-2] + self.exch[-1])
+
+    def iterate(self, iters, lr):
+        for _ in range(iters):
+            self.grad()
+            self.apply(lr)
+
+    def stress_history(self):
+        return numpy.array(self.hist)

@@ -1,0 +1,119 @@
+"""GPU: the multi-rank path with the real HIP kernels.
+
+* 2 processes share the single GPU of the test box, each playing one rank with
+  its own HipEngine; the all-reduce runs over gloo on host memory
+  (solver.allreduce_exchange_host) -- transport only.  The sharded result must
+  equal the single-rank GPU result within the config's fp tolerance (summation
+  order differs) and the replicas must be bit-identical.
+* 1 process, backend nccl (= RCCL), world_size 1: the device-resident path
+  (torch-allocated exchange tensor, solver on torch's stream) that the 8-GPU
+  run uses, rehearsed as far as one GPU allows.
+"""
+import os
+import socket
+import subprocess
+import sys
+import traceback
+
+import numpy
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, k, dtype, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import blueberry_amd as bb
+        from tests import _oracle
+        xs = _oracle.random_walk(n)
+        w = _oracle.wish_from_coords(xs)
+        s = bb.StructureSolver(n_iter=k, dtype=dtype, kind="wish", device=0)
+        s.fit(w, init=_oracle.noisy_init(xs))
+        band = bb.count_band_regions(_oracle.golden("band_count")["in_gappy_n5000"],
+                                     distributed=True)
+        q.put((rank, s.structure_, s.stress_, band))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, traceback.format_exc(), None, None))
+
+
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-12), ("float32", 1e-5)])
+def test_two_ranks_share_one_gpu(dtype, tol):
+    import torch.multiprocessing as mp
+    import blueberry_amd as bb
+    from tests import _oracle
+    n, k, world = 1300, 5, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, k, dtype, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert not isinstance(r[1], str), r[1]
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    one = bb.StructureSolver(n_iter=k, dtype=dtype, kind="wish", distributed=False)
+    one.fit(w, init=_oracle.noisy_init(xs))
+    for rank, X, hist, band in results:
+        assert numpy.abs(X - one.structure_).max() < tol * numpy.abs(one.structure_).max()
+        assert numpy.abs(hist / one.stress_ - 1).max() < tol
+        assert band == int(_oracle.golden("band_count")["out_gappy_n5000"])
+    assert numpy.array_equal(results[0][1], results[1][1])
+    assert numpy.array_equal(results[0][2], results[1][2])
+
+
+_NCCL_SCRIPT = r"""
+import os, sys, numpy
+sys.path.insert(0, %(root)r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%(port)d")
+import torch                       # BEFORE the first blueberry_amd compute call
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import blueberry_amd as bb
+from blueberry_amd import _lib
+from blueberry_amd.solver import HipEngine, run_iterations
+from tests import _oracle
+n, k = 900, 6
+xs = _oracle.random_walk(n); w = _oracle.wish_from_coords(xs); x0 = _oracle.noisy_init(xs)
+lr = 1.0 / (2 * n)
+out = {}
+for name, world in (("fused", 1), ("exchange", 2)):   # world=2 forces grad/all-reduce/apply
+    e = HipEngine(n, "float32")
+    e.set_wish_dense(w, "wish", 3.0); e.set_coords(x0)
+    run_iterations(e, k, lr, world)
+    out[name] = (e.get_coords(), e.stress_history()); e.close()
+assert len(_lib.hip_runtimes_loaded()) == 1, _lib.hip_runtimes_loaded()
+assert numpy.abs(out["fused"][0] - out["exchange"][0]).max() < 1e-5 * numpy.abs(out["fused"][0]).max()
+assert numpy.abs(out["fused"][1] / out["exchange"][1] - 1).max() < 1e-5
+dist.destroy_process_group()
+print("NCCL_PATH_OK")
+"""
+
+
+def test_rccl_single_rank_device_path():
+    script = _NCCL_SCRIPT % {"root": ROOT, "port": _free_port()}
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert "NCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
