@@ -88,6 +88,21 @@ def pmc_traffic(n_bins, dtype, world):
     return None
 
 
+class stdout_to_stderr(object):
+    """RCCL prints a version banner on fd 1 when its first communicator is made;
+    keep fd 1 for the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,8 +125,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+            warm = torch.zeros(1, device="cuda")
+            dist.all_reduce(warm)             # creates the communicator now
+            torch.cuda.synchronize()
 
     from blueberry_amd.solver import HipEngine, allreduce_exchange
 

@@ -827,9 +827,15 @@ int interleave() {
     return p2;
 }
 
-int waves_per_cu() {
+// Waves per CU (4 waves = one workgroup).  Measured on MI355X (profiles/
+// r01_sweeps.txt): with the rolling 8-KiB window one wave per SIMD already keeps
+// enough bytes in flight, and fewer, longer chunks mean fewer column-partial
+// slots and less prologue per byte: 4/CU wins below ~400k units per rank
+// (-12 % kernel time at 1/8 of the N=50k matrix), 4 and 8 tie above, 16 is
+// 2 % slower.  BB_WAVES_PER_CU overrides.
+int waves_per_cu(int64_t n_local) {
     const char *e = getenv("BB_WAVES_PER_CU");
-    int v = e ? atoi(e) : 16;
+    int v = e ? atoi(e) : (n_local >= 400000 ? 8 : 4);
     if (v < 1) v = 1;
     if (v > 32) v = 32;
     return v;
@@ -853,7 +859,7 @@ int build_indices(bb_solver *s) {
 
     int cus = 256;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
-    int64_t want = (int64_t)cus * waves_per_cu();
+    int64_t want = (int64_t)cus * waves_per_cu(s->n_local);
     int64_t nw = std::max<int64_t>(1, std::min<int64_t>(want, s->n_local));
     nw = bb::round_up(nw, 4);
     s->n_waves = (int)nw;
