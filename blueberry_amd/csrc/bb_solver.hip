@@ -690,6 +690,38 @@ __global__ __launch_bounds__(256) void convert_units_kernel(
     }
 }
 
+// Sparse (i, j, value) entries -> resident units (blocked-sparse input).  The
+// units were zeroed ("no constraint") first.  tilemap[I * n_blocks + J] is the
+// tile's index in the global list or -1.
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_entries_kernel(
+    const int64_t *__restrict__ rows, const int64_t *__restrict__ cols,
+    const double *__restrict__ vals, int64_t nnz, const int32_t *__restrict__ tilemap,
+    int64_t n_blocks, int64_t n_bins, int64_t u_begin, int64_t u_end, T *__restrict__ units,
+    int kind, double neg_inv_alpha, int *__restrict__ bad) {
+    constexpr int VW = Traits<T>::VW, RPU = Traits<T>::RPU, UPT = VW / RPU;
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nnz) return;
+    int64_t i = rows[k], j = cols[k];
+    if (i == j) return;                     // the diagonal carries no pair
+    if (i > j) { const int64_t t = i; i = j; j = t; }
+    if (i < 0 || j >= n_bins) { atomicExch(bad, 1); return; }
+    const int64_t I = i / VW, J = j / VW;
+    const int32_t t = tilemap[I * n_blocks + J];
+    if (t < 0) { atomicExch(bad, 2); return; }   // entry outside the tile list
+    const int64_t ri = i - I * VW;
+    const int64_t u = (int64_t)t * UPT + ri / RPU;
+    if (u < u_begin || u >= u_end) return;  // another rank's unit
+    double v = vals[k];
+    const bool ok = (v > 0.0) && (v <= 1.7976931348623157e308);
+    if (!ok)
+        v = 0.0;
+    else if (kind == BB_KIND_COUNTS)
+        v = pow(v, neg_inv_alpha);
+    if (sizeof(T) == 4 && v < 1e-30) v = 0.0;
+    units[(u - u_begin) * (RPU * VW) + (ri % RPU) * VW + (j - J * VW)] = (T)v;
+}
+
 // delta_ij = |x*_i - x*_j| generated in place (synthetic inputs).
 template <typename T>
 __global__ __launch_bounds__(256) void gen_units_kernel(const double *__restrict__ xs,
@@ -1228,6 +1260,80 @@ int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld, int k
                                 : set_wish_dense_t<double>(s, host, ld, kind, alpha);
     if (rc == BB_OK) s->have_wish = true;
     return rc;
+}
+
+int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *cols,
+                              const double *vals, int64_t nnz, int kind, double alpha) {
+    BB_REQUIRE(s != nullptr, "bb_solver_set_wish_sparse: solver is NULL");
+    BB_REQUIRE(nnz >= 0 && (nnz == 0 || (rows && cols && vals)),
+               "bb_solver_set_wish_sparse: NULL entries");
+    BB_REQUIRE(kind == BB_KIND_WISH || kind == BB_KIND_COUNTS, "bb_solver_set_wish_sparse: bad kind");
+    BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_sparse: alpha must be > 0");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    const int64_t nb = s->L.n_blocks;
+    std::vector<int32_t> tilemap((size_t)(nb * nb), -1);
+    for (size_t t = 0; t < s->tile_I.size(); ++t)
+        tilemap[(size_t)s->tile_I[t] * nb + s->tile_J[t]] = (int32_t)t;
+    int32_t *d_map = nullptr;
+    int *d_bad = nullptr;
+    int64_t *d_rows = nullptr, *d_cols = nullptr;
+    double *d_vals = nullptr;
+    constexpr int64_t kChunk = 1 << 22;  // entries staged per copy
+    const int64_t cap = std::max<int64_t>(1, std::min(nnz, kChunk));
+    int rc = dev_alloc(&d_map, nb * nb);
+    if (rc == BB_OK) rc = dev_alloc(&d_bad, 1);
+    if (rc == BB_OK) rc = dev_alloc(&d_rows, cap);
+    if (rc == BB_OK) rc = dev_alloc(&d_cols, cap);
+    if (rc == BB_OK) rc = dev_alloc(&d_vals, cap);
+    hipError_t e = hipSuccess;
+    int host_bad = 0;
+    if (rc == BB_OK) {
+        e = hipMemcpyAsync(d_map, tilemap.data(), tilemap.size() * sizeof(int32_t),
+                           hipMemcpyHostToDevice, s->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int), s->stream);
+        if (e == hipSuccess)
+            e = hipMemsetAsync(s->d_units, 0, (size_t)std::max<int64_t>(s->n_local, 1) * bb::kUnitBytes,
+                               s->stream);
+        for (int64_t k0 = 0; k0 < nnz && e == hipSuccess; k0 += kChunk) {
+            const int64_t m = std::min(kChunk, nnz - k0);
+            e = hipMemcpyAsync(d_rows, rows + k0, (size_t)m * 8, hipMemcpyHostToDevice, s->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(d_cols, cols + k0, (size_t)m * 8, hipMemcpyHostToDevice, s->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(d_vals, vals + k0, (size_t)m * 8, hipMemcpyHostToDevice, s->stream);
+            if (e != hipSuccess) break;
+            const unsigned grid = (unsigned)((m + 255) / 256);
+            if (s->dtype == BB_F32)
+                hipLaunchKernelGGL(scatter_entries_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
+                                   d_rows, d_cols, d_vals, m, d_map, nb, s->L.n_bins, s->u_begin,
+                                   s->u_end, (float *)s->d_units, kind, -1.0 / alpha, d_bad);
+            else
+                hipLaunchKernelGGL(scatter_entries_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
+                                   d_rows, d_cols, d_vals, m, d_map, nb, s->L.n_bins, s->u_begin,
+                                   s->u_end, (double *)s->d_units, kind, -1.0 / alpha, d_bad);
+            e = hipGetLastError();
+            // the staging buffers are reused by the next chunk: stream order makes that safe
+        }
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(&host_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    }
+    hipFree(d_map);
+    hipFree(d_bad);
+    hipFree(d_rows);
+    hipFree(d_cols);
+    hipFree(d_vals);
+    if (rc != BB_OK) return rc;
+    if (e != hipSuccess)
+        return bb::fail(BB_ERR_HIP, std::string("bb_solver_set_wish_sparse: ") + hipGetErrorString(e));
+    if (host_bad == 1)
+        return bb::fail(BB_ERR_INVALID, "bb_solver_set_wish_sparse: an index is outside [0, n_bins)");
+    if (host_bad == 2)
+        return bb::fail(BB_ERR_INVALID,
+                        "bb_solver_set_wish_sparse: an entry falls in a tile that is not in the "
+                        "solver's tile list");
+    s->have_wish = true;
+    return BB_OK;
 }
 
 int bb_solver_set_wish_from_coords(bb_solver *s, const double *xstar) {

@@ -72,6 +72,17 @@ class HipEngine(object):
             self._h, _lib.as_f64_ptr(m), m.strides[0] // 8, _KINDS[kind], float(alpha)),
             "bb_solver_set_wish_dense")
 
+    def set_wish_sparse(self, rows, cols, vals, kind, alpha):
+        r = numpy.ascontiguousarray(rows, dtype=numpy.int64)
+        c = numpy.ascontiguousarray(cols, dtype=numpy.int64)
+        v = numpy.ascontiguousarray(vals, dtype=numpy.float64)
+        if not (r.ndim == c.ndim == v.ndim == 1 and r.shape == c.shape == v.shape):
+            raise ValueError("rows, cols, vals must be 1-D arrays of equal length")
+        _lib.check(self._lib.bb_solver_set_wish_sparse(
+            self._h, r.ctypes.data_as(_lib.p_i64), c.ctypes.data_as(_lib.p_i64),
+            _lib.as_f64_ptr(v), r.shape[0], _KINDS[kind], float(alpha)),
+            "bb_solver_set_wish_sparse")
+
     def set_wish_from_coords(self, xstar):
         x = _check_coords(xstar, self.n_bins)
         _lib.check(self._lib.bb_solver_set_wish_from_coords(self._h, _lib.as_f64_ptr(x)),
@@ -206,6 +217,20 @@ def _check_coords(x, n_bins):
     return x
 
 
+def tiles_from_entries(n_bins, rows, cols, dtype):
+    """The (tile_I, tile_J) list -- device order: J ascending, then I -- of the
+    tiles that hold at least one entry (rows[k], cols[k]); either triangle."""
+    vw = 512 if dtype == "float32" else 128
+    r = numpy.asarray(rows, dtype=numpy.int64)
+    c = numpy.asarray(cols, dtype=numpy.int64)
+    if r.size and (min(r.min(), c.min()) < 0 or max(r.max(), c.max()) >= n_bins):
+        raise ValueError("an index is outside [0, n_bins)")
+    lo, hi = numpy.minimum(r, c) // vw, numpy.maximum(r, c) // vw
+    nb = (int(n_bins) + vw - 1) // vw
+    key = numpy.unique(hi * nb + lo)
+    return (key % nb).astype(numpy.int32), (key // nb).astype(numpy.int32)
+
+
 def allreduce_exchange(t):
     """Sum a device-resident exchange tensor over all ranks, in place: one
     all-reduce of 3*n_pad+2 elements (backend nccl = RCCL, over xGMI)."""
@@ -302,9 +327,15 @@ class StructureSolver(object):
         return int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
 
     def fit(self, X, init=None):
-        """Solve for the structure of `X` (a ContactMap or a square ndarray)."""
+        """Solve for the structure of `X`: a ContactMap, a square ndarray, or a
+        scipy.sparse matrix (symmetric; either triangle is enough, each pair
+        at most once) -- the sparse form never builds the dense matrix."""
         matrix = getattr(X, "matrix", X)
-        matrix = numpy.asarray(matrix)
+        sparse = hasattr(matrix, "tocoo")          # any scipy.sparse matrix
+        if sparse:
+            matrix = matrix.tocoo()
+        else:
+            matrix = numpy.asarray(matrix)
         if matrix.ndim != 2 or matrix.shape[0] != matrix.shape[1]:
             raise ValueError("contact matrix must be square, got shape %r" % (matrix.shape,))
         n = matrix.shape[0]
@@ -315,10 +346,19 @@ class StructureSolver(object):
         if init is None:
             init = numpy.random.default_rng(self.seed).standard_normal((n, 3))
 
+        tiles = None
+        if sparse:
+            # blocked-sparse: only the tiles that hold an entry exist on the device
+            keep = matrix.row != matrix.col
+            rows, cols, vals = matrix.row[keep], matrix.col[keep], matrix.data[keep]
+            tiles = tiles_from_entries(n, rows, cols, self.dtype)
         eng = self._engine_factory(n, self.dtype, rank=rank, world=world,
-                                   device=self._pick_device(world))
+                                   device=self._pick_device(world), tiles=tiles)
         try:
-            eng.set_wish_dense(matrix, self.kind, self.alpha)
+            if sparse:
+                eng.set_wish_sparse(rows, cols, vals, self.kind, self.alpha)
+            else:
+                eng.set_wish_dense(matrix, self.kind, self.alpha)
             eng.set_coords(init)
             run_iterations(eng, self.n_iter, lr, world)
             self.structure_ = eng.get_coords()

@@ -127,6 +127,15 @@ BB_API int bb_solver_layout(const bb_solver *s, bb_layout_info *info, int64_t *u
  * Each rank uploads only its own units. */
 BB_API int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld, int kind,
                                     double alpha);
+/* Blocked-sparse input: nnz entries (rows[k], cols[k], vals[k]) of the symmetric
+ * matrix, either triangle, each unordered pair at most once (if a pair occurs
+ * twice it is unspecified which value is kept).  Every entry must fall in a
+ * tile of the solver's tile list; all other pairs carry no constraint.  This
+ * is the form of the reference's own input files -- sparse (pos_i, pos_j,
+ * count) triples (blueberry/datatypes.pyx:31-38, :100-102) -- without the
+ * dense (n_bins+1)^2 host matrix, for genome-wide 10 kb maps (BASELINE config 5). */
+BB_API int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *cols,
+                                     const double *vals, int64_t nnz, int kind, double alpha);
 /* Synthetic input generated on the device: delta_ij = |x*_i - x*_j| for the
  * (n_bins,3) float64 host coordinates `xstar`, so that
  * N = 50k needs no 20 GB host matrix. */

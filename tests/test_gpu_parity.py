@@ -303,3 +303,55 @@ def test_errors():
     e.close()
     with pytest.raises(ValueError):
         HipEngine(10, "float32", device=99)
+
+
+# ---- blocked-sparse input (BASELINE config 5 shape, small) -------------------------
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-12), ("float32", 1e-5)])
+def test_solver_blocked_sparse_input(oracle, dtype, tol):
+    """A banded sparse matrix given as scipy COO: only tiles holding an entry are
+    resident; result equals the oracle run on the equivalent dense matrix."""
+    import scipy.sparse
+    n, k = 2200, 5
+    rng = numpy.random.default_rng(21)
+    xs = _oracle.random_walk(n)
+    i = rng.integers(0, n, 60000)
+    j = numpy.clip(i + rng.integers(1, 300, 60000), 0, n - 1)
+    keep = i != j
+    i, j = i[keep], j[keep]
+    key = numpy.unique(numpy.minimum(i, j) * n + numpy.maximum(i, j))   # each pair once
+    i, j = key // n, key % n
+    flip = rng.random(i.size) < 0.5                 # entries may sit in either triangle
+    r, c = numpy.where(flip, j, i), numpy.where(flip, i, j)
+    d = numpy.sqrt(((xs[i] - xs[j]) ** 2).sum(1)) * (1 + 0.1 * rng.standard_normal(i.size))
+    d = numpy.abs(d) + 0.05
+    sp = scipy.sparse.coo_matrix((d, (r, c)), shape=(n, n))
+    dense = numpy.zeros((n, n))
+    dense[i, j] = d
+    dense[j, i] = d
+    x0 = _oracle.noisy_init(xs)
+    lr = 1.0 / (2 * n)
+    X_ref, h_ref = oracle.solve(dense, x0, k, lr)
+    s = bb.StructureSolver(n_iter=k, lr=lr, dtype=dtype, kind="wish").fit(sp, init=x0)
+    assert numpy.abs(s.stress_ / h_ref - 1).max() < tol
+    assert _rel(s.structure_, X_ref) < tol
+    # far fewer tiles than the dense triangle
+    ti, tj = bb.solver.tiles_from_entries(n, r, c, dtype)
+    vw = 512 if dtype == "float32" else 128
+    nb = -(-n // vw)
+    assert len(ti) < nb * (nb + 1) // 2 or nb <= 5
+    assert (ti <= tj).all()
+
+
+def test_sparse_entry_outside_tile_list_is_an_error():
+    e = HipEngine(2000, "float64", tiles=(numpy.array([0]), numpy.array([0])))
+    with pytest.raises(ValueError, match="tile"):
+        e.set_wish_sparse([5], [1500], [1.0], "wish", 3.0)
+    with pytest.raises(ValueError, match="outside"):
+        e.set_wish_sparse([5], [2000], [1.0], "wish", 3.0)
+    e.set_wish_sparse([5, 7], [9, 7], [1.0, 3.0], "wish", 3.0)      # diagonal entry ignored
+    e.set_coords(numpy.arange(6000.0).reshape(2000, 3))
+    d59 = numpy.sqrt(3.0) * 12.0                                    # |x_5 - x_9|
+    assert abs(e.stress() - (d59 - 1.0) ** 2) < 1e-9
+    e.close()
+    with pytest.raises(ValueError):
+        HipEngine(2000, "float64", tiles=(numpy.array([1, 0]), numpy.array([1, 1])))  # bad order
