@@ -46,7 +46,8 @@ SIGNATURES = {
     "bb_solver_set_stream": (c_int, [c_void_p, c_void_p]),
     "bb_solver_layout": (c_int, [c_void_p, ctypes.POINTER(LayoutInfo), p_i64, p_i64]),
     "bb_solver_set_wish_dense": (c_int, [c_void_p, p_dbl, c_i64, c_int, c_dbl]),
-    "bb_solver_set_wish_sparse": (c_int, [c_void_p, p_i64, p_i64, p_dbl, c_i64, c_int, c_dbl]),
+    "bb_solver_set_wish_sparse": (c_int, [c_void_p, p_i64, p_i64, p_dbl, c_i64, c_int, c_dbl,
+                                          p_dbl, p_dbl]),
     "bb_solver_set_wish_from_coords": (c_int, [c_void_p, p_dbl]),
     "bb_solver_set_coords": (c_int, [c_void_p, p_dbl]),
     "bb_solver_get_coords": (c_int, [c_void_p, p_dbl]),

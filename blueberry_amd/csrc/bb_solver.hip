@@ -698,7 +698,8 @@ __global__ __launch_bounds__(256) void scatter_entries_kernel(
     const int64_t *__restrict__ rows, const int64_t *__restrict__ cols,
     const double *__restrict__ vals, int64_t nnz, const int32_t *__restrict__ tilemap,
     int64_t n_blocks, int64_t n_bins, int64_t u_begin, int64_t u_end, T *__restrict__ units,
-    int kind, double neg_inv_alpha, int *__restrict__ bad) {
+    int kind, double neg_inv_alpha, const double *__restrict__ kr,
+    const double *__restrict__ krexp, int *__restrict__ bad) {
     constexpr int VW = Traits<T>::VW, RPU = Traits<T>::RPU, UPT = VW / RPU;
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= nnz) return;
@@ -713,6 +714,9 @@ __global__ __launch_bounds__(256) void scatter_entries_kernel(
     const int64_t u = (int64_t)t * UPT + ri / RPU;
     if (u < u_begin || u >= u_end) return;  // another rank's unit
     double v = vals[k];
+    // KR balancing + observed/expected, the element-wise form of the loop at
+    // reference datatypes.pyx:166-169 (same operation order)
+    if (kr != nullptr) v = v / (kr[i] * kr[j] * krexp[j - i]);
     const bool ok = (v > 0.0) && (v <= 1.7976931348623157e308);
     if (!ok)
         v = 0.0;
@@ -1263,12 +1267,15 @@ int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld, int k
 }
 
 int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *cols,
-                              const double *vals, int64_t nnz, int kind, double alpha) {
+                              const double *vals, int64_t nnz, int kind, double alpha,
+                              const double *KRnorm, const double *KRexpected) {
     BB_REQUIRE(s != nullptr, "bb_solver_set_wish_sparse: solver is NULL");
     BB_REQUIRE(nnz >= 0 && (nnz == 0 || (rows && cols && vals)),
                "bb_solver_set_wish_sparse: NULL entries");
     BB_REQUIRE(kind == BB_KIND_WISH || kind == BB_KIND_COUNTS, "bb_solver_set_wish_sparse: bad kind");
     BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_sparse: alpha must be > 0");
+    BB_REQUIRE((KRnorm == nullptr) == (KRexpected == nullptr),
+               "bb_solver_set_wish_sparse: KRnorm and KRexpected go together");
     BB_HIP_CHECK(hipSetDevice(s->device));
     const int64_t nb = s->L.n_blocks;
     std::vector<int32_t> tilemap((size_t)(nb * nb), -1);
@@ -1277,7 +1284,7 @@ int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *
     int32_t *d_map = nullptr;
     int *d_bad = nullptr;
     int64_t *d_rows = nullptr, *d_cols = nullptr;
-    double *d_vals = nullptr;
+    double *d_vals = nullptr, *d_kr = nullptr, *d_ke = nullptr;
     constexpr int64_t kChunk = 1 << 22;  // entries staged per copy
     const int64_t cap = std::max<int64_t>(1, std::min(nnz, kChunk));
     int rc = dev_alloc(&d_map, nb * nb);
@@ -1285,11 +1292,18 @@ int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *
     if (rc == BB_OK) rc = dev_alloc(&d_rows, cap);
     if (rc == BB_OK) rc = dev_alloc(&d_cols, cap);
     if (rc == BB_OK) rc = dev_alloc(&d_vals, cap);
+    if (rc == BB_OK && KRnorm) rc = dev_alloc(&d_kr, s->L.n_bins);
+    if (rc == BB_OK && KRnorm) rc = dev_alloc(&d_ke, s->L.n_bins);
     hipError_t e = hipSuccess;
     int host_bad = 0;
     if (rc == BB_OK) {
         e = hipMemcpyAsync(d_map, tilemap.data(), tilemap.size() * sizeof(int32_t),
                            hipMemcpyHostToDevice, s->stream);
+        if (e == hipSuccess && KRnorm)
+            e = hipMemcpyAsync(d_kr, KRnorm, (size_t)s->L.n_bins * 8, hipMemcpyHostToDevice, s->stream);
+        if (e == hipSuccess && KRnorm)
+            e = hipMemcpyAsync(d_ke, KRexpected, (size_t)s->L.n_bins * 8, hipMemcpyHostToDevice,
+                               s->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int), s->stream);
         if (e == hipSuccess)
             e = hipMemsetAsync(s->d_units, 0, (size_t)std::max<int64_t>(s->n_local, 1) * bb::kUnitBytes,
@@ -1306,11 +1320,13 @@ int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *
             if (s->dtype == BB_F32)
                 hipLaunchKernelGGL(scatter_entries_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
                                    d_rows, d_cols, d_vals, m, d_map, nb, s->L.n_bins, s->u_begin,
-                                   s->u_end, (float *)s->d_units, kind, -1.0 / alpha, d_bad);
+                                   s->u_end, (float *)s->d_units, kind, -1.0 / alpha, d_kr, d_ke,
+                                   d_bad);
             else
                 hipLaunchKernelGGL(scatter_entries_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
                                    d_rows, d_cols, d_vals, m, d_map, nb, s->L.n_bins, s->u_begin,
-                                   s->u_end, (double *)s->d_units, kind, -1.0 / alpha, d_bad);
+                                   s->u_end, (double *)s->d_units, kind, -1.0 / alpha, d_kr, d_ke,
+                                   d_bad);
             e = hipGetLastError();
             // the staging buffers are reused by the next chunk: stream order makes that safe
         }
@@ -1323,6 +1339,8 @@ int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *
     hipFree(d_rows);
     hipFree(d_cols);
     hipFree(d_vals);
+    hipFree(d_kr);
+    hipFree(d_ke);
     if (rc != BB_OK) return rc;
     if (e != hipSuccess)
         return bb::fail(BB_ERR_HIP, std::string("bb_solver_set_wish_sparse: ") + hipGetErrorString(e));

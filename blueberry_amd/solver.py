@@ -72,16 +72,22 @@ class HipEngine(object):
             self._h, _lib.as_f64_ptr(m), m.strides[0] // 8, _KINDS[kind], float(alpha)),
             "bb_solver_set_wish_dense")
 
-    def set_wish_sparse(self, rows, cols, vals, kind, alpha):
+    def set_wish_sparse(self, rows, cols, vals, kind, alpha, KRnorm=None, KRexpected=None):
         r = numpy.ascontiguousarray(rows, dtype=numpy.int64)
         c = numpy.ascontiguousarray(cols, dtype=numpy.int64)
         v = numpy.ascontiguousarray(vals, dtype=numpy.float64)
         if not (r.ndim == c.ndim == v.ndim == 1 and r.shape == c.shape == v.shape):
             raise ValueError("rows, cols, vals must be 1-D arrays of equal length")
+        kr = ke = None
+        if KRnorm is not None or KRexpected is not None:
+            if KRnorm is None or KRexpected is None:
+                raise ValueError("KRnorm and KRexpected go together")
+            kr, ke = _pad_vector(KRnorm, self.n_bins), _pad_vector(KRexpected, self.n_bins)
         _lib.check(self._lib.bb_solver_set_wish_sparse(
             self._h, r.ctypes.data_as(_lib.p_i64), c.ctypes.data_as(_lib.p_i64),
-            _lib.as_f64_ptr(v), r.shape[0], _KINDS[kind], float(alpha)),
-            "bb_solver_set_wish_sparse")
+            _lib.as_f64_ptr(v), r.shape[0], _KINDS[kind], float(alpha),
+            None if kr is None else _lib.as_f64_ptr(kr),
+            None if ke is None else _lib.as_f64_ptr(ke)), "bb_solver_set_wish_sparse")
 
     def set_wish_from_coords(self, xstar):
         x = _check_coords(xstar, self.n_bins)
@@ -206,6 +212,17 @@ def _check_square(matrix, n_bins):
     if m.dtype != numpy.float64 or m.strides[1] != 8 or m.strides[0] % 8 or m.strides[0] < 8 * n_bins:
         m = numpy.ascontiguousarray(m, dtype=numpy.float64)
     return m
+
+
+def _pad_vector(v, n):
+    """KR vectors have n_bins entries, the matrix n_bins+1 bins: pad with NaN
+    (a NaN divisor = no constraint, as for unmappable bins in Rao's files)."""
+    v = numpy.asarray(v, dtype=numpy.float64).ravel()
+    if v.shape[0] > n:
+        raise ValueError("KR vector longer than the number of bins")
+    out = numpy.full(n, numpy.nan)
+    out[:v.shape[0]] = v
+    return out
 
 
 def _check_coords(x, n_bins):
@@ -339,6 +356,10 @@ class StructureSolver(object):
         if matrix.ndim != 2 or matrix.shape[0] != matrix.shape[1]:
             raise ValueError("contact matrix must be square, got shape %r" % (matrix.shape,))
         n = matrix.shape[0]
+        return self._fit_impl(matrix, n, init, None, None)
+
+    def _fit_impl(self, matrix, n, init, KRnorm, KRexpected):
+        sparse = hasattr(matrix, "row")
         if n < 2:
             raise ValueError("need at least 2 bins")
         rank, world = _dist_state(self.distributed)
@@ -356,7 +377,7 @@ class StructureSolver(object):
                                    device=self._pick_device(world), tiles=tiles)
         try:
             if sparse:
-                eng.set_wish_sparse(rows, cols, vals, self.kind, self.alpha)
+                eng.set_wish_sparse(rows, cols, vals, self.kind, self.alpha, KRnorm, KRexpected)
             else:
                 eng.set_wish_dense(matrix, self.kind, self.alpha)
             eng.set_coords(init)
@@ -367,6 +388,28 @@ class StructureSolver(object):
             eng.close()
         self.n_bins_, self.lr_ = n, lr
         return self
+
+    def fit_triples(self, triples, resolution, n_bins, KRnorm=None, KRexpected=None, init=None):
+        """Solve straight from a Rao-format sparse file's content, never building
+        the dense matrix: `triples` is the (n, 3) array [pos_i, pos_j, count] that
+        `ContactMap.__init__` reads (reference `blueberry/datatypes.pyx:100-102`),
+        bins are `int(pos / resolution)` (pyx:111-112), the matrix has
+        `n_bins + 1` bins (pyx:97), and with KRnorm / KRexpected each count is
+        balanced and O/E-normalised on the device as `ContactMap.normalize`
+        would (pyx:166-169).  Each bin pair may occur once."""
+        t = numpy.nan_to_num(numpy.asarray(triples, dtype=numpy.float64))       # pyx:102
+        if t.ndim != 2 or t.shape[1] != 3:
+            raise ValueError("triples must have shape (n, 3)")
+        n = int(n_bins) + 1
+        rows = (t[:, 0] / resolution).astype(numpy.int64)
+        cols = (t[:, 1] / resolution).astype(numpy.int64)
+        if KRnorm is not None and (numpy.any(numpy.asarray(KRnorm) == 0.0)
+                                   or numpy.any(numpy.asarray(KRexpected)[:n_bins] == 0.0)):
+            raise ZeroDivisionError("float division")      # as ContactMap.normalize
+        import scipy.sparse
+        keep = rows != cols
+        sp = scipy.sparse.coo_matrix((t[keep, 2], (rows[keep], cols[keep])), shape=(n, n))
+        return self._fit_impl(sp, n, init, KRnorm, KRexpected)
 
     def fit_transform(self, X, init=None):
         """`fit(X)` and return the (n_bins, 3) coordinates."""

@@ -133,9 +133,15 @@ BB_API int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld
  * tile of the solver's tile list; all other pairs carry no constraint.  This
  * is the form of the reference's own input files -- sparse (pos_i, pos_j,
  * count) triples (blueberry/datatypes.pyx:31-38, :100-102) -- without the
- * dense (n_bins+1)^2 host matrix, for genome-wide 10 kb maps (BASELINE config 5). */
+ * dense (n_bins+1)^2 host matrix, for genome-wide 10 kb maps (BASELINE config 5).
+ * KRnorm / KRexpected (n_bins doubles each, or both NULL): each value is first
+ * divided by KRnorm[i] * KRnorm[j] * KRexpected[j - i] (i < j), the element-wise
+ * form of ContactMap.normalize (blueberry/datatypes.pyx:166-169); a NaN or
+ * non-finite quotient means "no constraint" (the reference's nan_to_num gives
+ * 0 for NaN as well). */
 BB_API int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *cols,
-                                     const double *vals, int64_t nnz, int kind, double alpha);
+                                     const double *vals, int64_t nnz, int kind, double alpha,
+                                     const double *KRnorm, const double *KRexpected);
 /* Synthetic input generated on the device: delta_ij = |x*_i - x*_j| for the
  * (n_bins,3) float64 host coordinates `xstar`, so that
  * N = 50k needs no 20 GB host matrix. */

@@ -403,3 +403,45 @@ def test_genome_10kb_sized_blocked_band_properties():
     g_full, g_sum = full[:3 * n], acc[:3 * n]
     assert numpy.abs(g_sum - g_full).max() < 1e-5 * numpy.abs(g_full).max()
     assert abs((acc[-2] + acc[-1]) / (full[-2] + full[-1]) - 1) < 1e-6
+
+
+def test_fit_triples_equals_contactmap_pipeline(oracle):
+    """Rao-format triples + KR vectors straight to the solver (normalisation and
+    count->distance on the device, no dense matrix) equals: ContactMap scatter
+    -> normalize() -> dense fit, and equals the oracle's restatement of that
+    whole chain (datatypes.pyx:100-116, :161-171, then SPEC 2)."""
+    rng = numpy.random.default_rng(8)
+    n_bins, res, k = 700, 10000, 5
+    bi = rng.integers(0, n_bins, 40000)
+    bj = numpy.minimum(n_bins - 1, bi + rng.geometric(0.02, 40000))
+    key = numpy.unique(bi * n_bins + bj)                       # each bin pair once
+    bi, bj = key // n_bins, key % n_bins
+    counts = rng.integers(1, 400, bi.size).astype(float)
+    triples = numpy.stack([bi * float(res), bj * float(res), counts], 1)
+    kr = 0.5 + rng.random(n_bins)
+    kr[rng.random(n_bins) < 0.05] = numpy.nan
+    ke = 40.0 / (1.0 + numpy.arange(n_bins)) + 0.2
+    n = n_bins + 1
+    x0 = numpy.random.default_rng(1).standard_normal((n, 3))
+    lr = 1.0 / (2 * n)
+
+    raw = oracle.contactmap_scatter(triples, res, n_bins)
+    norm = oracle.contactmap_normalize(raw, kr, ke)
+    wish = oracle.counts_to_wish(norm, 3.0)
+    X_ref, h_ref = oracle.solve(wish, x0, k, lr)
+
+    cm = bb.ContactMap.from_matrix(bb.datatypes.scatter_triples(triples, res, n_bins),
+                                   resolution=res, KRnorm=kr, KRexpected=ke)
+    cm.normalize()
+    assert numpy.array_equal(cm.matrix, norm)
+    for dtype, tol in (("float64", 1e-12), ("float32", 1e-5)):
+        dense = bb.StructureSolver(n_iter=k, lr=lr, dtype=dtype).fit(cm, init=x0)
+        direct = bb.StructureSolver(n_iter=k, lr=lr, dtype=dtype).fit_triples(
+            triples, res, n_bins, KRnorm=kr, KRexpected=ke, init=x0)
+        for s in (dense, direct):
+            assert numpy.abs(s.stress_ / h_ref - 1).max() < tol, dtype
+            assert _rel(s.structure_, X_ref) < tol, dtype
+    with pytest.raises(ZeroDivisionError):
+        kr0 = kr.copy()
+        kr0[3] = 0.0
+        bb.StructureSolver(n_iter=1).fit_triples(triples, res, n_bins, KRnorm=kr0, KRexpected=ke)
