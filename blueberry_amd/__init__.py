@@ -5,6 +5,8 @@ Drop-in names (same meaning as in `blueberry.*`, reference
 `blueberry/__init__.py:38-43` star-exports):
     count_band_regions            blueberry/blueberry.pyx:77-91
     ContactMap                    blueberry/datatypes.pyx:31-272
+    benjamini_hochberg            blueberry/blueberry.pyx:40-75
+    downsample                    blueberry/blueberry.pyx:93-104
     Q_LOWER_BOUND, Q_UPPER_BOUND, HIGH_FITHIC_CUTOFF, LOW_FITHIC_CUTOFF
                                   blueberry/utils.py:23-26
 Net-new (the reference has no solver; docs/SPEC.md):
@@ -20,5 +22,6 @@ from .utils import (HIGH_FITHIC_CUTOFF, LOW_FITHIC_CUTOFF, Q_LOWER_BOUND,  # noq
 from .band import count_band_regions  # noqa: F401
 from .datatypes import ContactMap  # noqa: F401
 from .solver import HipEngine, StructureSolver  # noqa: F401
+from .stats import benjamini_hochberg, downsample  # noqa: F401
 
 __version__ = "0.1.0"

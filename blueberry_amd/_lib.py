@@ -68,6 +68,9 @@ SIGNATURES = {
     "bb_solver_traffic": (c_int, [c_void_p, p_i64, p_i64]),
     "bb_contactmap_scatter": (c_int, [p_dbl, c_i64, c_i32, p_dbl, c_i64, c_int]),
     "bb_contactmap_normalize": (c_int, [p_dbl, c_i64, p_dbl, p_dbl, c_int]),
+    "bb_benjamini_hochberg": (c_int, [p_dbl, c_i64, c_i64, p_dbl, c_int]),
+    "bb_downsample": (c_int, [ctypes.POINTER(ctypes.c_float), c_i64,
+                              ctypes.POINTER(ctypes.c_float), c_i64, c_int]),
 }
 
 _lib = None

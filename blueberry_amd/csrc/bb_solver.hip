@@ -300,7 +300,7 @@ __device__ __forceinline__ void pair_step2(f32x2 delta, f32x2 xi, f32x2 yi, f32x
 
 // d[] holds the unit's 8 wave-loads in row order: d[2*r + k] = row r, load k.
 template <bool NT>
-__device__ __forceinline__ void process_unit_f32(float4 (&d)[8], float xrow,
+__device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&xrow)[12],
                                                  const float4 *__restrict__ next, StripF32 &st,
                                                  double &stress, __amdgpu_buffer_rsrc_t row_rsrc,
                                                  unsigned row_voff) {
@@ -314,8 +314,7 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], float xrow,
     float keep = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float xs = lane_value(xrow, 3 * r), ys = lane_value(xrow, 3 * r + 1),
-                    zs = lane_value(xrow, 3 * r + 2);
+        const float xs = xrow[3 * r], ys = xrow[3 * r + 1], zs = xrow[3 * r + 2];
         const f32x2 xi = {xs, xs}, yi = {ys, ys}, zi = {zs, zs};
         f32x2 rx, ry, rz, qx, qy, qz;  // row-side sums of load 0 / load 1
         pair_step2<0, 0, true>(f32x2{d[2 * r].x, d[2 * r].y}, xi, yi, zi, st, rx, ry, rz, s2);
@@ -482,7 +481,29 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
         int2 dc = udesc[ua];                                   // current unit
         int2 dn = udesc[ua + stride < ub ? ua + stride : ua];  // next unit
         // Prologue: the x rows of the first unit, then its 8 matrix rows.
-        T xr = load_xrow<T>(X, dc.x, lane);
+        // Row coordinates of a unit.  fp32: 12 wave-uniform scalars fetched through
+        // the scalar cache (X is read-only in this kernel), one unit ahead -- no
+        // VMEM slot, no v_readlane.  fp64: one per-lane load + v_readlane (24
+        // doubles, double-buffered, would not fit the SGPR file).
+        struct XRowS { float v[12]; };
+        struct XRowV { T v; };
+#ifdef BB_ABL_XROW_VECTOR
+        using XRow = XRowV;
+#else
+        using XRow = typename std::conditional<sizeof(T) == 4, XRowS, XRowV>::type;
+#endif
+        auto xrow_load = [&](int i0) __attribute__((always_inline)) {
+            XRow x;
+            if constexpr (std::is_same<XRow, XRowS>::value) {
+                const float *px = reinterpret_cast<const float *>(X) + (int64_t)i0 * 3;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) x.v[q] = px[q];
+            } else {
+                x.v = load_xrow<T>(X, i0, lane);
+            }
+            return x;
+        };
+        XRow xr = xrow_load(dc.x);
         {
             const Vec *first = unit_ptr<T>(units, ua, lane);
 #pragma unroll
@@ -497,7 +518,7 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
         auto unit_step = [&](int u) __attribute__((always_inline)) {
             // the wave's last unit "prefetches" itself: harmless, stays in bounds
             const int un = u + stride < ub ? u + stride : u;
-            const T xrn = load_xrow<T>(X, dn.x, lane);
+            const XRow xrn = xrow_load(dn.x);
             const int2 dnn = udesc[un + stride < ub ? un + stride : un];
             unsigned row_voff;
             if constexpr (sizeof(T) == 4)   // fp32: lanes 48..59 store one of the 12 sums each
@@ -506,11 +527,20 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
                                : kDropOffset;
             else                            // fp64: lane 63 stores each row's three sums
                 row_voff = lane == 63 ? (unsigned)(u - ua) * kRowBytes : kDropOffset;
-            if constexpr (sizeof(T) == 4)
-                process_unit_f32<NT>(d, xr, unit_ptr<T>(units, un, lane), st, stress, row_rsrc,
+            if constexpr (sizeof(T) == 4) {
+#ifdef BB_ABL_XROW_VECTOR
+                float xs12[12];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) xs12[q] = lane_value(xr.v, q);
+                process_unit_f32<NT>(d, xs12, unit_ptr<T>(units, un, lane), st, stress, row_rsrc,
                                      row_voff);
+#else
+                process_unit_f32<NT>(d, xr.v, unit_ptr<T>(units, un, lane), st, stress, row_rsrc,
+                                     row_voff);
+#endif
+            }
             else
-                process_unit<T, NT>(d, xr, unit_ptr<T>(units, un, lane), st.xj, st.gc, stress,
+                process_unit<T, NT>(d, xr.v, unit_ptr<T>(units, un, lane), st.xj, st.gc, stress,
                                     row_rsrc, row_voff);
             xr = xrn;
             dc = dn;
@@ -548,6 +578,8 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
 // --------------------------------------------------------------------------
 // reduce (+ update) kernel: one workgroup per vw-bin block
 // --------------------------------------------------------------------------
+constexpr int kReduceSlice = 16;  // chunks per stage-1 slice = chunks loaded per round trip
+
 enum ReduceMode {
     kReduceApply = 0,      // X -= lr * 2 * sum
     kReduceExchange = 1,   // exch = 2 * sum (+ stress hi/lo)
@@ -582,31 +614,25 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
         T acc[NE];
 #pragma unroll
         for (int j = 0; j < NE; ++j) acc[j] = T(0);
-        // chunks are summed in list order (deterministic); 4 chunks = 4*NE loads in flight
-        int64_t k = k0;
-        for (; k + 4 <= k1; k += 4) {
-            const T *s0 = p.part + p.blk_chunk[k], *s1 = p.part + p.blk_chunk[k + 1],
-                    *s2 = p.part + p.blk_chunk[k + 2], *s3 = p.part + p.blk_chunk[k + 3];
-            T v0[NE], v1[NE], v2[NE], v3[NE];
+        // Chunks are summed in list order (deterministic).  A whole slice of up to
+        // kReduceSlice chunks is loaded before the first add, so a slice costs one
+        // memory round trip, not one per chunk: this kernel is latency-bound.
+        for (int64_t k = k0; k < k1; k += kReduceSlice) {
+            T v[kReduceSlice][NE];
 #pragma unroll
-            for (int j = 0; j < NE; ++j) {
-                const int e = tid + 256 * j;
-                const bool ok = e < CH;
-                v0[j] = ok ? s0[e] : T(0);
-                v1[j] = ok ? s1[e] : T(0);
-                v2[j] = ok ? s2[e] : T(0);
-                v3[j] = ok ? s3[e] : T(0);
+            for (int q = 0; q < kReduceSlice; ++q) {
+                const bool on = k + q < k1;
+                const T *src = p.part + p.blk_chunk[on ? k + q : k0];
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int e = tid + 256 * j;
+                    v[q][j] = (on && e < CH) ? src[e] : T(0);
+                }
             }
 #pragma unroll
-            for (int j = 0; j < NE; ++j) acc[j] = (((acc[j] + v0[j]) + v1[j]) + v2[j]) + v3[j];
-        }
-        for (; k < k1; ++k) {
-            const T *src = p.part + p.blk_chunk[k];
+            for (int q = 0; q < kReduceSlice; ++q)
 #pragma unroll
-            for (int j = 0; j < NE; ++j) {
-                const int e = tid + 256 * j;
-                if (e < CH) acc[j] += src[e];
-            }
+                for (int j = 0; j < NE; ++j) acc[j] += v[q][j];
         }
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
@@ -956,7 +982,7 @@ int build_indices(bb_solver *s) {
     // Two-stage reduce: a block's list can hold hundreds of chunks (one per strip
     // of its tile row).  Lists longer than kSlice are cut into slices that stage 1
     // sums in parallel into `part2`; the final stage then sums the slice results.
-    constexpr int64_t kSlice = 16;
+    constexpr int64_t kSlice = kReduceSlice;
     std::vector<int64_t> s1_ptr(1, 0), s1_chunk, fin_ptr(nb + 1, 0), fin_chunk;
     s->part2_off = s->rowpart_elems + s->colpart_elems;
     for (int64_t b = 0; b < nb; ++b) {

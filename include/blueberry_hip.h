@@ -211,6 +211,18 @@ BB_API int bb_contactmap_scatter(const double *triples, int64_t n, int32_t resol
 BB_API int bb_contactmap_normalize(double *matrix, int64_t n_bins, const double *KRnorm,
                                    const double *KRexpected, int device);
 
+/* ---------------------------------------------------------------------- */
+/* The remaining numeric Cython helpers of blueberry.pyx                    */
+/* ---------------------------------------------------------------------- */
+
+/* q[i] = max_{k<=i} min(p[k] * n / (k+1), 1) for d sorted p-values and n tests
+ * (reference: blueberry/blueberry.pyx:40-75; a parallel prefix-max, exact). */
+BB_API int bb_benjamini_hochberg(const double *p_values, int64_t d, int64_t n, double *q_values,
+                                 int device);
+/* yp5i (n5,n5) float32, in place: yp5i[i][j] = max(yp5i[i][j], 5x5 block of yp1
+ * (n1,n1)) for i, j < n5-1 (reference: blueberry/blueberry.pyx:93-104). */
+BB_API int bb_downsample(const float *yp1, int64_t n1, float *yp5i, int64_t n5, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -445,3 +445,38 @@ def test_fit_triples_equals_contactmap_pipeline(oracle):
         kr0 = kr.copy()
         kr0[3] = 0.0
         bb.StructureSolver(n_iter=1).fit_triples(triples, res, n_bins, KRnorm=kr0, KRexpected=ke)
+
+
+# ---- the two remaining numeric helpers of blueberry.pyx ---------------------------
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_bh_golden_bit_exact(k):
+    z = _oracle.golden("bh_downsample")
+    q = bb.benjamini_hochberg(z["bh_p_%d" % k], int(z["bh_n_%d" % k]))
+    assert numpy.array_equal(q, z["bh_q_%d" % k])
+
+
+@pytest.mark.parametrize("d", [1, 255, 1024, 1025, 300000, 2000003])
+def test_bh_vs_oracle_ragged(oracle, d):
+    rng = numpy.random.default_rng(d)
+    p = numpy.sort(rng.random(d) ** 4)
+    n = int(d * 3.7) + 5
+    assert numpy.array_equal(bb.benjamini_hochberg(p, n), oracle.benjamini_hochberg(p, n))
+    assert bb.benjamini_hochberg(numpy.zeros(0), 10).shape == (0,)
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_downsample_golden_bit_exact(k):
+    z = _oracle.golden("bh_downsample")
+    yp5i = z["ds_yp5i_%d" % k].copy()
+    out = bb.downsample(z["ds_yp1_%d" % k], numpy.zeros_like(yp5i), yp5i)
+    assert numpy.array_equal(out, z["ds_out_%d" % k])
+    assert numpy.array_equal(yp5i, out)                    # in place, like the reference
+
+
+def test_downsample_vs_oracle_ragged(oracle):
+    rng = numpy.random.default_rng(5)
+    for n5 in (1, 2, 17, 33, 200):
+        yp1 = rng.standard_normal((n5 * 5 + 3, n5 * 5 + 3)).astype(numpy.float32)
+        yp5i = rng.standard_normal((n5, n5)).astype(numpy.float32)
+        want = oracle.downsample(yp1, yp5i)
+        assert numpy.array_equal(bb.downsample(yp1, yp5i, yp5i.copy()), want)
