@@ -51,6 +51,7 @@ SIGNATURES = {
     "bb_solver_set_wish_from_coords": (c_int, [c_void_p, p_dbl]),
     "bb_solver_set_coords": (c_int, [c_void_p, p_dbl]),
     "bb_solver_get_coords": (c_int, [c_void_p, p_dbl]),
+    "bb_solver_set_momentum": (c_int, [c_void_p, c_dbl]),
     "bb_solver_iterate": (c_int, [c_void_p, c_i64, c_dbl]),
     "bb_solver_grad": (c_int, [c_void_p]),
     "bb_solver_apply": (c_int, [c_void_p, c_dbl]),

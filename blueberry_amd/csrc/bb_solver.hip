@@ -594,6 +594,8 @@ struct ReduceParams {
     const int64_t *__restrict__ blk_chunk;   // element offsets into part
     const double *__restrict__ stresspart;
     T *__restrict__ X;                       // apply mode
+    T *__restrict__ V;                       // apply mode: velocity (heavy-ball momentum)
+    T mu;                                    // momentum coefficient, 0 = plain gradient step
     T *__restrict__ exch;                    // exchange mode: [3*n_pad | hi | lo]
     T *__restrict__ part_out;                // partial mode: CH elements per workgroup
     double *__restrict__ stress_out;         // apply / stress-only: where the stress goes
@@ -643,10 +645,14 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
                     p.part_out[o] = acc[j];
                 } else {
                     const T g = T(2) * acc[j];
-                    if (p.mode == kReduceApply)
-                        p.X[o] -= p.lr * g;
-                    else
+                    if (p.mode == kReduceApply) {
+                        // SPEC 2.4: V <- mu V - lr g ; X <- X + V   (mu = 0: X -= lr g)
+                        const T v = p.mu * p.V[o] - p.lr * g;
+                        p.V[o] = v;
+                        p.X[o] += v;
+                    } else {
                         p.exch[o] = g;
+                    }
                 }
             }
         }
@@ -676,10 +682,15 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void apply_kernel(T *__restrict__ X, const T *__restrict__ exch,
-                                                    int64_t n3, T lr, double *stress_out) {
+__global__ __launch_bounds__(256) void apply_kernel(T *__restrict__ X, T *__restrict__ V,
+                                                    const T *__restrict__ exch, int64_t n3, T lr,
+                                                    T mu, double *stress_out) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e < n3) X[e] -= lr * exch[e];
+    if (e < n3) {
+        const T v = mu * V[e] - lr * exch[e];
+        V[e] = v;
+        X[e] += v;
+    }
     if (e == 0 && stress_out) *stress_out = (double)exch[n3] + (double)exch[n3 + 1];
 }
 
@@ -835,7 +846,8 @@ struct bb_solver {
     hipStream_t stream = nullptr;
     bool own_stream = false;
 
-    void *d_units = nullptr, *d_X = nullptr, *d_part = nullptr, *d_exch = nullptr;
+    void *d_units = nullptr, *d_X = nullptr, *d_V = nullptr, *d_part = nullptr, *d_exch = nullptr;
+    double momentum = 0.0;
     bool own_exch = false;
     int2 *d_udesc = nullptr;
     int2 *d_wave_range = nullptr;
@@ -1007,6 +1019,7 @@ int build_indices(bb_solver *s) {
     const int64_t es = bb::elem_size(s->dtype);
     BB_TRY(dev_alloc((char **)&s->d_units, std::max<int64_t>(s->n_local, 1) * bb::kUnitBytes));
     BB_TRY(dev_alloc((char **)&s->d_X, s->L.n_pad * 3 * es));
+    BB_TRY(dev_alloc((char **)&s->d_V, s->L.n_pad * 3 * es));
     BB_TRY(dev_alloc((char **)&s->d_part, part_total * es));
     BB_TRY(dev_alloc(&s->d_udesc, (int64_t)s->udesc.size()));
     BB_TRY(dev_alloc(&s->d_wave_range, nw));
@@ -1041,6 +1054,7 @@ int build_indices(bb_solver *s) {
     // rows of boundary tiles owned by another rank are never written: keep them 0
     BB_HIP_CHECK(hipMemsetAsync(s->d_part, 0, (size_t)part_total * es, st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_X, 0, (size_t)(s->L.n_pad * 3 * es), st));
+    BB_HIP_CHECK(hipMemsetAsync(s->d_V, 0, (size_t)(s->L.n_pad * 3 * es), st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_exch, 0, (size_t)((3 * s->L.n_pad + 2) * es), st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_stresspart, 0, (size_t)nw * sizeof(double), st));
     BB_HIP_CHECK(hipStreamSynchronize(st));  // the host vectors above die with this scope
@@ -1074,6 +1088,8 @@ int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out) {
     p.part = (const T *)s->d_part;
     p.stresspart = s->d_stresspart;
     p.X = (T *)s->d_X;
+    p.V = (T *)s->d_V;
+    p.mu = (T)s->momentum;
     p.exch = (T *)s->d_exch;
     p.part_out = (T *)s->d_part + s->part2_off;
     p.stress_out = stress_out;
@@ -1242,6 +1258,7 @@ int bb_solver_destroy(bb_solver *s) {
     for (hipEvent_t e : s->ev) hipEventDestroy(e);
     hipFree(s->d_units);
     hipFree(s->d_X);
+    hipFree(s->d_V);
     hipFree(s->d_part);
     if (s->own_exch) hipFree(s->d_exch);
     hipFree(s->d_udesc);
@@ -1417,6 +1434,7 @@ int bb_solver_set_coords(bb_solver *s, const double *xyz) {
         hipLaunchKernelGGL(f64_to_T_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
                            s->d_f64_tmp, (double *)s->d_X, n3);
     BB_HIP_CHECK(hipGetLastError());
+    BB_HIP_CHECK(hipMemsetAsync(s->d_V, 0, (size_t)n3 * bb::elem_size(s->dtype), s->stream));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     s->have_coords = true;
     s->hist_n = 0;
@@ -1440,6 +1458,13 @@ int bb_solver_get_coords(bb_solver *s, double *xyz) {
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     BB_HIP_CHECK(hipMemcpy(xyz, s->d_f64_tmp, (size_t)s->L.n_bins * 3 * sizeof(double),
                            hipMemcpyDeviceToHost));
+    return BB_OK;
+}
+
+int bb_solver_set_momentum(bb_solver *s, double mu) {
+    BB_REQUIRE(s != nullptr, "bb_solver_set_momentum: solver is NULL");
+    BB_REQUIRE(mu >= 0.0 && mu < 1.0, "bb_solver_set_momentum: need 0 <= mu < 1");
+    s->momentum = mu;
     return BB_OK;
 }
 
@@ -1489,12 +1514,12 @@ int bb_solver_apply(bb_solver *s, double lr) {
     const unsigned grid = (unsigned)((n3 + 255) / 256);
     if (s->dtype == BB_F32)
         hipLaunchKernelGGL(apply_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
-                           (float *)s->d_X, (const float *)s->d_exch, n3, (float)lr,
-                           s->d_stress_hist + s->hist_n);
+                           (float *)s->d_X, (float *)s->d_V, (const float *)s->d_exch, n3,
+                           (float)lr, (float)s->momentum, s->d_stress_hist + s->hist_n);
     else
         hipLaunchKernelGGL(apply_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
-                           (double *)s->d_X, (const double *)s->d_exch, n3, lr,
-                           s->d_stress_hist + s->hist_n);
+                           (double *)s->d_X, (double *)s->d_V, (const double *)s->d_exch, n3, lr,
+                           s->momentum, s->d_stress_hist + s->hist_n);
     BB_HIP_CHECK(hipGetLastError());
     s->hist_n++;
     s->grad_pending = false;

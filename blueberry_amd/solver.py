@@ -106,6 +106,9 @@ class HipEngine(object):
         return out
 
     # -- iterations -------------------------------------------------------
+    def set_momentum(self, mu):
+        _lib.check(self._lib.bb_solver_set_momentum(self._h, float(mu)), "bb_solver_set_momentum")
+
     def iterate(self, iters, lr):
         _lib.check(self._lib.bb_solver_iterate(self._h, int(iters), float(lr)),
                    "bb_solver_iterate")
@@ -306,6 +309,8 @@ class StructureSolver(object):
         Whether the input matrix holds contact counts or wish distances.
     seed : int
         Seed of the default initial coordinates (numpy default_rng standard normal).
+    momentum : float in [0, 1)
+        Heavy-ball coefficient mu: V <- mu V - lr g, X <- X + V.  0 = plain steps.
     device : int or None
         HIP device index; None = LOCAL_RANK (distributed) or 0.
     distributed : bool or None
@@ -320,7 +325,7 @@ class StructureSolver(object):
     """
 
     def __init__(self, n_iter=100, lr="auto", dtype="float32", alpha=3.0, kind="counts",
-                 seed=0, device=None, distributed=None, engine=None):
+                 seed=0, device=None, distributed=None, engine=None, momentum=0.0):
         if dtype not in _DTYPES:
             raise ValueError("dtype must be 'float32' or 'float64'")
         if kind not in _KINDS:
@@ -331,6 +336,9 @@ class StructureSolver(object):
             raise ValueError("lr must be positive or 'auto'")
         if not float(alpha) > 0:
             raise ValueError("alpha must be positive")
+        if not 0.0 <= float(momentum) < 1.0:
+            raise ValueError("momentum must be in [0, 1)")
+        self.momentum = float(momentum)
         self.n_iter, self.lr, self.dtype, self.alpha, self.kind, self.seed = (
             int(n_iter), lr, dtype, float(alpha), kind, int(seed))
         self.device, self.distributed = device, distributed
@@ -381,6 +389,8 @@ class StructureSolver(object):
             else:
                 eng.set_wish_dense(matrix, self.kind, self.alpha)
             eng.set_coords(init)
+            if self.momentum:
+                eng.set_momentum(self.momentum)
             run_iterations(eng, self.n_iter, lr, world)
             self.structure_ = eng.get_coords()
             self.stress_ = eng.stress_history()

@@ -150,8 +150,12 @@ BB_API int bb_solver_set_wish_from_coords(bb_solver *s, const double *xstar);
 BB_API int bb_solver_set_coords(bb_solver *s, const double *xyz); /* (n_bins,3) f64 host */
 BB_API int bb_solver_get_coords(bb_solver *s, double *xyz);
 
-/* world = 1: `iters` iterations of { stress + gradient, X <- X - lr * g },
- * enqueued back to back; stress history is kept on the device. */
+/* Heavy-ball momentum (SPEC 2.4): V <- mu V - lr g, X <- X + V, V = 0 after
+ * bb_solver_set_coords.  mu = 0 (the default) is the plain gradient step. */
+BB_API int bb_solver_set_momentum(bb_solver *s, double mu);
+
+/* world = 1: `iters` iterations of { stress + gradient, update }, enqueued
+ * back to back; stress history is kept on the device. */
 BB_API int bb_solver_iterate(bb_solver *s, int64_t iters, double lr);
 
 /* world > 1 (also valid for world = 1): one iteration in two halves around

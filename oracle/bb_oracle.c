@@ -215,6 +215,24 @@ BBO_API void bbo_solve(const double *wish, long n, long ld, double *X, long iter
     }
 }
 
+/* SPEC 2.4 with heavy-ball momentum: V <- mu V - lr g, X <- X + V, V_0 = 0.
+ * `scratch` is (2n,3): gradient then velocity. */
+BBO_API void bbo_solve_momentum(const double *wish, long n, long ld, double *X, long iters,
+                                double lr, double mu, int eps2_kind, double *stress_hist,
+                                double *scratch)
+{
+    double *g = scratch, *V = scratch + 3 * n;
+    memset(V, 0, sizeof(double) * 3 * (size_t)n);
+    for (long k = 0; k < iters; k++) {
+        double s = bbo_stress_grad(wish, n, ld, X, eps2_kind, g);
+        if (stress_hist) stress_hist[k] = s;
+        for (long e = 0; e < 3 * n; e++) {
+            V[e] = mu * V[e] - lr * g[e];
+            X[e] += V[e];
+        }
+    }
+}
+
 /* The pairs owned by a contiguous range of "units" of the device layout
  * (docs/SPEC.md 3; include/blueberry_hip.h bb_layout_*): unit u belongs to
  * tile t = u / units_per_tile with block coordinates (tile_I[t], tile_J[t]),

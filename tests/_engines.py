@@ -30,6 +30,7 @@ class OracleEngine(object):
         self.oracle = _oracle.load()
         self.exch = numpy.zeros(3 * self.info.n_pad + 2)
         self.hist = []
+        self.mu = 0.0
 
     def close(self):
         pass
@@ -38,8 +39,12 @@ class OracleEngine(object):
         m = numpy.ascontiguousarray(matrix, dtype=numpy.float64)
         self.w = self.oracle.counts_to_wish(m, alpha) if kind == "counts" else m
 
+    def set_momentum(self, mu):
+        self.mu = float(mu)
+
     def set_coords(self, x0):
         self.X = numpy.ascontiguousarray(x0, dtype=numpy.float64).copy()
+        self.V = numpy.zeros_like(self.X)
         self.hist = []
 
     def get_coords(self):
@@ -60,7 +65,8 @@ class OracleEngine(object):
         self.exch[:] = host
 
     def apply(self, lr):
-        self.X -= lr * self.exch[:3 * self.n_bins].reshape(self.n_bins, 3)
+        self.V = self.mu * self.V - lr * self.exch[:3 * self.n_bins].reshape(self.n_bins, 3)
+        self.X += self.V
         self.hist.append(self.exch[-2] + self.exch[-1])
 
     def iterate(self, iters, lr):

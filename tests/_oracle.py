@@ -44,6 +44,9 @@ class Oracle(object):
         L.bbo_stress_grad.argtypes = [p_dbl, c_long, c_long, p_dbl, c_int, p_dbl]
         L.bbo_solve.restype = None
         L.bbo_solve.argtypes = [p_dbl, c_long, c_long, p_dbl, c_long, c_dbl, c_int, p_dbl, p_dbl]
+        L.bbo_solve_momentum.restype = None
+        L.bbo_solve_momentum.argtypes = [p_dbl, c_long, c_long, p_dbl, c_long, c_dbl, c_dbl,
+                                         c_int, p_dbl, p_dbl]
         L.bbo_stress_grad_units.restype = c_dbl
         L.bbo_stress_grad_units.argtypes = [p_dbl, c_long, c_long, p_dbl, c_int, p_i32, p_i32,
                                             c_long, c_long, c_long, c_long, p_dbl]
@@ -108,6 +111,15 @@ class Oracle(object):
         g = numpy.zeros_like(X)
         self.lib.bbo_solve(_p(w), w.shape[0], w.shape[1], _p(X), int(iters), float(lr),
                            1 if f64 else 0, _p(hist), _p(g))
+        return X, hist
+
+    def solve_momentum(self, wish, X0, iters, lr, mu, f64=True):
+        w = numpy.ascontiguousarray(wish, dtype=numpy.float64)
+        X = numpy.ascontiguousarray(X0, dtype=numpy.float64).copy()
+        hist = numpy.zeros(iters)
+        scratch = numpy.zeros((2 * X.shape[0], 3))
+        self.lib.bbo_solve_momentum(_p(w), w.shape[0], w.shape[1], _p(X), int(iters), float(lr),
+                                    float(mu), 1 if f64 else 0, _p(hist), _p(scratch))
         return X, hist
 
     def stress_grad_units(self, wish, X, tile_I, tile_J, upt, vw, u_begin, u_end, f64=True):

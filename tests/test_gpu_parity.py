@@ -480,3 +480,47 @@ def test_downsample_vs_oracle_ragged(oracle):
         yp5i = rng.standard_normal((n5, n5)).astype(numpy.float32)
         want = oracle.downsample(yp1, yp5i)
         assert numpy.array_equal(bb.downsample(yp1, yp5i, yp5i.copy()), want)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The boundary is a C ABI: compile examples/solve.c with gcc (no HIP
+    headers, no Python) against the header and the .so, and run it."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "bb_solve")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "solve.c"), "-o", exe,
+                           "-L" + os.path.join(root, "blueberry_amd"), "-lblueberry_hip",
+                           "-Wl,-rpath," + os.path.join(root, "blueberry_amd"), "-lm"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "C-ABI OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("mu", [0.3, 0.6])
+def test_solver_momentum_matches_oracle(oracle, mu):
+    """SPEC 2.4 heavy-ball step, fused path and grad/apply path, both dtypes."""
+    n, k = 900, 12
+    xs, w, x0 = _problem(n)
+    lr = 1.0 / (2 * n)
+    X_ref, h_ref = oracle.solve_momentum(w, x0, k, lr, mu)
+    assert h_ref[-1] < oracle.solve(w, x0, k, lr)[1][-1]          # it does accelerate
+    for dtype, tol in (("float64", 1e-12), ("float32", 2e-5)):
+        s = bb.StructureSolver(n_iter=k, lr=lr, dtype=dtype, kind="wish", momentum=mu)
+        s.fit(w, init=x0)
+        assert numpy.abs(s.stress_ / h_ref - 1).max() < tol
+        assert _rel(s.structure_, X_ref) < tol
+    e = HipEngine(n, "float64")
+    e.set_wish_dense(w, "wish", 3.0)
+    e.set_coords(x0)
+    e.set_momentum(mu)
+    for _ in range(k):
+        e.grad()
+        e.apply(lr)
+    assert _rel(e.get_coords(), X_ref) < 1e-12
+    e.set_coords(x0)                                             # velocity is reset
+    e.iterate(k, lr)
+    assert _rel(e.get_coords(), X_ref) < 1e-12
+    e.close()
+    with pytest.raises(ValueError):
+        bb.StructureSolver(momentum=1.0)

@@ -163,3 +163,12 @@ def test_units_partition_sums_to_full(oracle):
             g_sum += g
         assert abs(s_sum - s_full) <= 1e-12 * s_full
         assert numpy.abs(g_sum - g_full).max() <= 1e-12 * numpy.abs(g_full).max()
+
+
+def test_momentum_zero_is_plain_solve(oracle):
+    n = 60
+    xs = _oracle.random_walk(n)
+    w, x0 = _oracle.wish_from_coords(xs), _oracle.noisy_init(xs)
+    a = oracle.solve(w, x0, 9, 1.0 / (2 * n))
+    b = oracle.solve_momentum(w, x0, 9, 1.0 / (2 * n), 0.0)
+    assert numpy.array_equal(a[0], b[0]) and numpy.array_equal(a[1], b[1])
