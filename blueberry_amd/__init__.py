@@ -5,6 +5,7 @@ Drop-in names (same meaning as in `blueberry.*`, reference
 `blueberry/__init__.py:38-43` star-exports):
     count_band_regions            blueberry/blueberry.pyx:77-91
     ContactMap                    blueberry/datatypes.pyx:31-272
+    FithicContactMap              blueberry/datatypes.pyx:274-388
     benjamini_hochberg            blueberry/blueberry.pyx:40-75
     downsample                    blueberry/blueberry.pyx:93-104
     Q_LOWER_BOUND, Q_UPPER_BOUND, HIGH_FITHIC_CUTOFF, LOW_FITHIC_CUTOFF
@@ -20,7 +21,7 @@ missing -- there is no CPU fallback.
 from .utils import (HIGH_FITHIC_CUTOFF, LOW_FITHIC_CUTOFF, Q_LOWER_BOUND,  # noqa: F401
                     Q_UPPER_BOUND)
 from .band import count_band_regions  # noqa: F401
-from .datatypes import ContactMap  # noqa: F401
+from .datatypes import ContactMap, FithicContactMap  # noqa: F401
 from .solver import HipEngine, StructureSolver  # noqa: F401
 from .stats import benjamini_hochberg, downsample  # noqa: F401
 

@@ -217,3 +217,111 @@ class ContactMap(object):
         import scipy.sparse.linalg
         _, eigenvectors = scipy.sparse.linalg.eigsh(self.matrix, k=1)
         return eigenvectors[:, 0]
+
+
+DATA_DIR = RAO + ("results/Rao-Cell2014/fixedWindowSize/fithic/afterICE/{2}/"
+                  "{0}.chr{1}.spline_pass1.res{2}.significances.txt.gz")
+
+
+class FithicContactMap(object):
+    """A contact map which has been processed with Fit-Hi-C.
+
+    Same surface as the reference class (`blueberry/datatypes.pyx:274-388`):
+    `map` is an (n_contacts, 5) float64 array of (mid1, mid2, contactCount, p, q)
+    read from columns [1, 3, 4, 5, 6] of a `.significances.txt.gz` file (format
+    written at `blueberry/fithic.py:411`), `regions` the midpoints seen.  It is
+    the on-disk adapter that lets real Fit-Hi-C output feed `StructureSolver`:
+    `to_sparse()` gives the scipy matrix `fit()` takes without ever building the
+    dense one.
+
+    Deviations: `decimate` uses the integer arithmetic the
+    Python 2 reference meant (`(int + res) // res * res - res // 2`) and emits
+    rows sorted by (mid1, mid2) instead of in dict order; `to_matrix` takes an
+    optional `n_bins` instead of always reading the KRnorm file; `from_array`
+    builds a map without a file.
+    """
+
+    def __init__(self, celltype, chromosome, resolution=1000):
+        import pandas
+        self.resolution = int(resolution)
+        self.filename = DATA_DIR.format(celltype, chromosome, self.resolution)
+        self.chromosome = chromosome
+        self.celltype = celltype
+        self.map = pandas.read_csv(self.filename, sep="\t", usecols=[1, 3, 4, 5, 6], engine="c",
+                                   dtype="float64").values
+        self.regions = numpy.union1d(self.map[:, 0], self.map[:, 1])
+
+    @classmethod
+    def from_array(cls, map_array, resolution, celltype="", chromosome=0):
+        self = cls.__new__(cls)
+        m = numpy.array(map_array, dtype=numpy.float64)
+        if m.ndim != 2 or m.shape[1] != 5:
+            raise ValueError("map must have shape (n_contacts, 5): mid1, mid2, count, p, q")
+        self.map, self.resolution = m, int(resolution)
+        self.filename, self.celltype, self.chromosome = "", celltype, chromosome
+        self.regions = numpy.union1d(m[:, 0], m[:, 1])
+        return self
+
+    def decimate(self, resolution=5000):
+        """Decimate the map to a lower resolution: midpoints are rounded to the
+        coarser grid, counts summed, p-values multiplied, q-values minimised
+        (`blueberry/datatypes.pyx:317-339`).  In place, returns None."""
+        resolution = int(resolution)
+        self.resolution = resolution
+        mids = (self.map[:, :2].astype(numpy.int64) + resolution) // resolution * resolution \
+            - resolution // 2
+        key, inv = numpy.unique(mids, axis=0, return_inverse=True)
+        inv = inv.ravel()
+        count = numpy.zeros(key.shape[0])
+        numpy.add.at(count, inv, self.map[:, 2])
+        p = numpy.ones(key.shape[0])
+        numpy.multiply.at(p, inv, self.map[:, 3])
+        q = numpy.ones(key.shape[0])
+        numpy.minimum.at(q, inv, self.map[:, 4])
+        self.map = numpy.column_stack([key.astype(numpy.float64), count, p, q])
+        self.regions = numpy.union1d(self.map[:, 0], self.map[:, 1])
+
+    def contacts(self):
+        """All contacts with a q-value <= Q_LOWER_BOUND, as (mid1, mid2) rows
+        (`blueberry/datatypes.pyx:341-350`)."""
+        from .utils import Q_LOWER_BOUND
+        return self.map[self.map[:, 4] <= Q_LOWER_BOUND, :2]
+
+    def _bins(self):
+        res = self.resolution
+        b1 = ((self.map[:, 0] - res / 2.0) / res).astype(numpy.int64)
+        b2 = ((self.map[:, 1] - res / 2.0) / res).astype(numpy.int64)
+        return b1, b2
+
+    def _statistic(self, statistic):
+        col = {"count": 2, "p": 3, "q": 4}.get(statistic)
+        if col is None:
+            raise ValueError                     # as the reference (pyx:386)
+        return self.map[:, col]
+
+    def to_matrix(self, statistic="count", n_bins=None):
+        """Convert the map from column format to a 2d (n_bins+1)^2 matrix holding
+        `statistic` at [bin(mid1), bin(mid2)] (one triangle, as the reference
+        fills it; `blueberry/datatypes.pyx:352-388`)."""
+        vals = self._statistic(statistic)
+        if n_bins is None:
+            kr = numpy.loadtxt(KR_NORM.format(self.celltype, self.chromosome,
+                                              self.resolution // 1000))
+            n_bins = numpy.atleast_1d(kr).shape[0]
+        d = int(n_bins) + 1
+        b1, b2 = self._bins()
+        matrix = numpy.zeros((d, d))
+        for k in range(b1.shape[0]):             # later rows win, as in the reference
+            matrix[b1[k], b2[k]] = vals[k]
+        return matrix
+
+    def to_sparse(self, statistic="count", n_bins=None):
+        """The same content as a scipy.sparse COO matrix of shape (n_bins+1)^2 --
+        what `StructureSolver.fit` takes for blocked-sparse input."""
+        import scipy.sparse
+        vals = self._statistic(statistic)
+        b1, b2 = self._bins()
+        if n_bins is None:
+            n_bins = int(max(b1.max(initial=0), b2.max(initial=0)))
+        d = int(n_bins) + 1
+        return scipy.sparse.coo_matrix((vals, (b1, b2)), shape=(d, d))

@@ -20,6 +20,7 @@ Functions captured (reference file:line):
   downsample              blueberry/blueberry.pyx:93-104
   ContactMap.__init__     blueberry/datatypes.pyx:88-120
   ContactMap.normalize    blueberry/datatypes.pyx:143-171
+  FithicContactMap        blueberry/datatypes.pyx:274-388 (__init__, contacts, to_matrix)
 """
 import os
 import shutil
@@ -149,6 +150,39 @@ def make_contactmap(dt, tmp):
     print("contactmap cases written")
 
 
+def make_fithic(dt, tmp):
+    """FithicContactMap (datatypes.pyx:274-388) on a synthetic Fit-Hi-C output
+    file (format: fithic.py:411 header, 7 tab-separated columns, gzip)."""
+    import gzip
+    rng = numpy.random.default_rng(4)
+    data_dir = os.path.join(tmp, "fithic")
+    os.makedirs(data_dir)
+    dt.DATA_DIR = os.path.join(data_dir, "{0}.chr{1}.res{2}.significances.txt.gz")
+    dt.KR_NORM = os.path.join(data_dir, "{0}_chr{1}_{2}kb.KRnorm")
+    n_bins, res, n = 40, 5000, 300
+    b1 = rng.integers(0, n_bins, n)
+    b2 = numpy.minimum(n_bins - 1, b1 + rng.integers(1, 12, n))
+    key = numpy.unique(b1 * n_bins + b2)
+    b1, b2 = key // n_bins, key % n_bins
+    mid1, mid2 = b1 * res + res // 2, b2 * res + res // 2
+    cc = rng.integers(1, 90, b1.size)
+    pv = rng.random(b1.size) ** 3
+    qv = numpy.minimum(1.0, pv * 4)
+    path = dt.DATA_DIR.format("cellF", 7, res)
+    with gzip.open(path, "wt") as fh:
+        fh.write("chr1\tfragmentMid1\tchr2\tfragmentMid2\tcontactCount\tp-value\tq-value\n")
+        for k in range(b1.size):
+            fh.write("7\t%d\t7\t%d\t%d\t%.10e\t%.10e\n" % (mid1[k], mid2[k], cc[k], pv[k], qv[k]))
+    numpy.savetxt(dt.KR_NORM.format("cellF", 7, res / 1000), numpy.ones(n_bins))
+    fm = dt.FithicContactMap("cellF", 7, res)
+    out = {"fh_map": fm.map.copy(), "fh_regions": fm.regions.copy(), "fh_contacts": fm.contacts(),
+           "fh_resolution": numpy.int64(res), "fh_n_bins": numpy.int64(n_bins)}
+    for stat in ("count", "p", "q"):
+        out["fh_matrix_" + stat] = fm.to_matrix(stat)
+    numpy.savez_compressed(os.path.join(OUT, "fithic_map.npz"), **out)
+    print("fithic map cases written", fm.map.shape, out["fh_contacts"].shape)
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="bbref_")
     try:
@@ -156,6 +190,7 @@ def main():
         make_band(bb)
         make_bh_downsample(bb)
         make_contactmap(dt, tmp)
+        make_fithic(dt, tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
         shutil.rmtree(os.path.expanduser("~/.pyxbld"), ignore_errors=True)

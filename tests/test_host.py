@@ -205,3 +205,43 @@ def test_contactmap_correlation_and_eigenvector_host_paths():
     assert abs(abs(v @ V[:, -1]) - 1) < 1e-8
     assert cm.correlation() is None
     assert numpy.allclose(cm.matrix, numpy.corrcoef(a + a.T))
+
+
+# ---- FithicContactMap (datatypes.pyx:274-388) against the real reference ----------
+def test_fithic_map_matches_reference_golden(tmp_path):
+    import gzip
+    from tests import _oracle
+    z = _oracle.golden("fithic_map")
+    res, n_bins = int(z["fh_resolution"]), int(z["fh_n_bins"])
+    # through a file, like the reference's constructor
+    path = tmp_path / ("x.chr7.spline_pass1.res%d.significances.txt.gz" % res)
+    with gzip.open(str(path), "wt") as fh:
+        fh.write("chr1\tfragmentMid1\tchr2\tfragmentMid2\tcontactCount\tp-value\tq-value\n")
+        for m1, m2, c, p, q in z["fh_map"]:
+            fh.write("7\t%d\t7\t%d\t%d\t%.17e\t%.17e\n" % (m1, m2, c, p, q))
+    old = bb.datatypes.DATA_DIR
+    bb.datatypes.DATA_DIR = str(tmp_path / "{0}.chr{1}.spline_pass1.res{2}.significances.txt.gz")
+    try:
+        fm = bb.FithicContactMap("x", 7, res)
+    finally:
+        bb.datatypes.DATA_DIR = old
+    assert numpy.array_equal(fm.map, z["fh_map"]) and numpy.array_equal(fm.regions, z["fh_regions"])
+    assert numpy.array_equal(fm.contacts(), z["fh_contacts"])
+    for stat in ("count", "p", "q"):
+        assert numpy.array_equal(fm.to_matrix(stat, n_bins=n_bins), z["fh_matrix_" + stat])
+        sp = fm.to_sparse(stat, n_bins=n_bins)
+        assert numpy.array_equal(sp.toarray(), z["fh_matrix_" + stat])
+    with pytest.raises(ValueError):
+        fm.to_matrix("z", n_bins=n_bins)
+
+
+def test_fithic_decimate_py2_semantics():
+    # two 1 kb contacts that fall in the same 5 kb pair of bins, one that does not
+    m = numpy.array([[500.0, 6500.0, 3, 0.1, 0.5],
+                     [1500.0, 7500.0, 4, 0.2, 0.3],
+                     [500.0, 11500.0, 5, 0.5, 1.0]])
+    fm = bb.FithicContactMap.from_array(m, 1000)
+    assert fm.decimate(5000) is None and fm.resolution == 5000
+    # (int + 5000) // 5000 * 5000 - 2500: 500 -> 2500, 1500 -> 2500, 6500/7500 -> 7500, 11500 -> 12500
+    want = numpy.array([[2500.0, 7500.0, 7.0, 0.1 * 0.2, 0.3], [2500.0, 12500.0, 5.0, 0.5, 1.0]])
+    assert numpy.allclose(fm.map, want) and numpy.array_equal(fm.regions, [2500.0, 7500.0, 12500.0])
