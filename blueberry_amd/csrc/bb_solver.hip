@@ -162,12 +162,25 @@ __device__ __forceinline__ void store_row3(__amdgpu_buffer_rsrc_t rsrc, unsigned
 // --------------------------------------------------------------------------
 // stress + gradient kernel
 // --------------------------------------------------------------------------
+// What the sweep computes per pair (i, j), template parameter OP:
+//   kOpStress : residual force of SPEC 2.3 -> gradient (row and column side) + stress
+//   kOpMatvec2: y_i += delta_ij^2 * x_j and y_j += delta_ij^2 * x_i for three
+//               right-hand sides held in the coordinate slots: Y = (D o D) X, the
+//               kernel of classical-MDS / spectral initialisation
+enum { kOpStress = 0, kOpMatvec2 = 1 };
+
 // Pair math for one matrix row of a unit: VPL pairs per lane.
-template <typename T, int C>
+template <typename T, int C, int OP>
 __device__ __forceinline__ void pair_step(const typename Traits<T>::Vec &drow, T xi, T yi, T zi,
                                           const T (&xj)[Traits<T>::VPL][3],
                                           T (&gc)[Traits<T>::VPL][3], T &gx, T &gy, T &gz, T &s) {
     const T delta = elem<C>(drow);
+    if constexpr (OP == kOpMatvec2) {
+        const T a = delta * delta;
+        gx += a * xj[C][0]; gy += a * xj[C][1]; gz += a * xj[C][2];
+        gc[C][0] += a * xi; gc[C][1] += a * yi; gc[C][2] += a * zi;
+        return;
+    }
     const T dx = xi - xj[C][0], dy = yi - xj[C][1], dz = zi - xj[C][2];
     const T d2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, Traits<T>::eps2())));  // SPEC 2.2
     T rinv, dist;
@@ -212,7 +225,7 @@ __device__ __forceinline__ double2 stream_load(const double2 *p) {
 // One unit (8 matrix rows).  Row r of the CURRENT unit is consumed from d[r],
 // then d[r] is immediately refilled with row r of the NEXT unit, so 8 KiB per
 // wave stay in flight with a single 8-row register buffer.
-template <typename T, bool NT>
+template <typename T, bool NT, int OP>
 __device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[Traits<T>::RPU], T xrow,
                                              const typename Traits<T>::Vec *__restrict__ next,
                                              const T (&xj)[Traits<T>::VPL][3],
@@ -226,11 +239,11 @@ __device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[Traits
         const T xi = lane_value(xrow, 3 * r), yi = lane_value(xrow, 3 * r + 1),
                 zi = lane_value(xrow, 3 * r + 2);
         T gx = T(0), gy = T(0), gz = T(0);
-        pair_step<T, 0>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
-        pair_step<T, 1>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
+        pair_step<T, 0, OP>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
+        pair_step<T, 1, OP>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
         if constexpr (VPL == 4) {
-            pair_step<T, 2>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
-            pair_step<T, 3>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
+            pair_step<T, 2, OP>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
+            pair_step<T, 3, OP>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
         }
         d[r] = stream_load<NT>(next + r * 64);
         wave_sum_hi3(gx, gy, gz);
@@ -266,9 +279,21 @@ __device__ __forceinline__ f32x2 weight01(f32x2 delta) {
     return w;
 }
 
-template <int K, int H, bool FIRST>
+template <int K, int H, bool FIRST, int OP>
 __device__ __forceinline__ void pair_step2(f32x2 delta, f32x2 xi, f32x2 yi, f32x2 zi, StripF32 &st,
                                            f32x2 &rx, f32x2 &ry, f32x2 &rz, f32x2 &s2) {
+    if constexpr (OP == kOpMatvec2) {
+        const f32x2 a = delta * delta;
+        if constexpr (FIRST) {
+            rx = a * st.x[K][H][0]; ry = a * st.x[K][H][1]; rz = a * st.x[K][H][2];
+        } else {
+            rx += a * st.x[K][H][0]; ry += a * st.x[K][H][1]; rz += a * st.x[K][H][2];
+        }
+        st.g[K][H][0] += a * xi;
+        st.g[K][H][1] += a * yi;
+        st.g[K][H][2] += a * zi;
+        return;
+    }
     const f32x2 eps2 = {1e-30f, 1e-30f};
     const f32x2 dx = xi - st.x[K][H][0], dy = yi - st.x[K][H][1], dz = zi - st.x[K][H][2];
     const f32x2 d2 = dx * dx + (dy * dy + (dz * dz + eps2));  // SPEC 2.2: |d|^2 + eps^2
@@ -299,7 +324,7 @@ __device__ __forceinline__ void pair_step2(f32x2 delta, f32x2 xi, f32x2 yi, f32x
 }
 
 // d[] holds the unit's 8 wave-loads in row order: d[2*r + k] = row r, load k.
-template <bool NT>
+template <bool NT, int OP>
 __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&xrow)[12],
                                                  const float4 *__restrict__ next, StripF32 &st,
                                                  double &stress, __amdgpu_buffer_rsrc_t row_rsrc,
@@ -317,15 +342,15 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&x
         const float xs = xrow[3 * r], ys = xrow[3 * r + 1], zs = xrow[3 * r + 2];
         const f32x2 xi = {xs, xs}, yi = {ys, ys}, zi = {zs, zs};
         f32x2 rx, ry, rz, qx, qy, qz;  // row-side sums of load 0 / load 1
-        pair_step2<0, 0, true>(f32x2{d[2 * r].x, d[2 * r].y}, xi, yi, zi, st, rx, ry, rz, s2);
-        pair_step2<0, 1, false>(f32x2{d[2 * r].z, d[2 * r].w}, xi, yi, zi, st, rx, ry, rz, s2);
+        pair_step2<0, 0, true, OP>(f32x2{d[2 * r].x, d[2 * r].y}, xi, yi, zi, st, rx, ry, rz, s2);
+        pair_step2<0, 1, false, OP>(f32x2{d[2 * r].z, d[2 * r].w}, xi, yi, zi, st, rx, ry, rz, s2);
         d[2 * r] = stream_load<NT>(next + (2 * r) * 64);
         // three scheduling regions per row (load 0 | load 1 | reduce+store): inside a
         // region the two halves interleave, which hides the 1-wait-state hazard
         // between dependent v_pk_* ops that costs an s_nop when they run back to back
         __builtin_amdgcn_sched_barrier(0);
-        pair_step2<1, 0, true>(f32x2{d[2 * r + 1].x, d[2 * r + 1].y}, xi, yi, zi, st, qx, qy, qz, s2);
-        pair_step2<1, 1, false>(f32x2{d[2 * r + 1].z, d[2 * r + 1].w}, xi, yi, zi, st, qx, qy, qz, s2);
+        pair_step2<1, 0, true, OP>(f32x2{d[2 * r + 1].x, d[2 * r + 1].y}, xi, yi, zi, st, qx, qy, qz, s2);
+        pair_step2<1, 1, false, OP>(f32x2{d[2 * r + 1].z, d[2 * r + 1].w}, xi, yi, zi, st, qx, qy, qz, s2);
         d[2 * r + 1] = stream_load<NT>(next + (2 * r + 1) * 64);
         __builtin_amdgcn_sched_barrier(0);
         rx += qx; ry += qy; rz += qz;
@@ -440,7 +465,7 @@ __device__ __forceinline__ void store_strip(const T (&gc)[Traits<T>::VPL][3],
 //   rowpart    3*RPU elements per unit, base shifted to the rank's first tile
 //   colpart    3*VW elements per slot
 //   stresspart one double per wave
-template <typename T, bool NT>
+template <typename T, bool NT, int OP>
 __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
     const T *__restrict__ units, const T *__restrict__ X, const int2 *__restrict__ udesc,
     const int2 *__restrict__ wave_range, const int32_t *__restrict__ wave_slot,
@@ -532,15 +557,15 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
                 float xs12[12];
 #pragma unroll
                 for (int q = 0; q < 12; ++q) xs12[q] = lane_value(xr.v, q);
-                process_unit_f32<NT>(d, xs12, unit_ptr<T>(units, un, lane), st, stress, row_rsrc,
+                process_unit_f32<NT, OP>(d, xs12, unit_ptr<T>(units, un, lane), st, stress, row_rsrc,
                                      row_voff);
 #else
-                process_unit_f32<NT>(d, xr.v, unit_ptr<T>(units, un, lane), st, stress, row_rsrc,
+                process_unit_f32<NT, OP>(d, xr.v, unit_ptr<T>(units, un, lane), st, stress, row_rsrc,
                                      row_voff);
 #endif
             }
             else
-                process_unit<T, NT>(d, xr.v, unit_ptr<T>(units, un, lane), st.xj, st.gc, stress,
+                process_unit<T, NT, OP>(d, xr.v, unit_ptr<T>(units, un, lane), st.xj, st.gc, stress,
                                     row_rsrc, row_voff);
             xr = xrn;
             dc = dn;
@@ -596,6 +621,7 @@ struct ReduceParams {
     T *__restrict__ X;                       // apply mode
     T *__restrict__ V;                       // apply mode: velocity (heavy-ball momentum)
     T mu;                                    // momentum coefficient, 0 = plain gradient step
+    T scale;                                 // 2 for the gradient (SPEC 2.3), 1 for a matvec
     T *__restrict__ exch;                    // exchange mode: [3*n_pad | hi | lo]
     T *__restrict__ part_out;                // partial mode: CH elements per workgroup
     double *__restrict__ stress_out;         // apply / stress-only: where the stress goes
@@ -644,7 +670,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
                 if (p.mode == kReducePartial) {
                     p.part_out[o] = acc[j];
                 } else {
-                    const T g = T(2) * acc[j];
+                    const T g = p.scale * acc[j];
                     if (p.mode == kReduceApply) {
                         // SPEC 2.4: V <- mu V - lr g ; X <- X + V   (mu = 0: X -= lr g)
                         const T v = p.mu * p.V[o] - p.lr * g;
@@ -1062,34 +1088,37 @@ int build_indices(bb_solver *s) {
 }
 
 template <typename T>
-int launch_grad_t(bb_solver *s) {
+int launch_grad_t(bb_solver *s, int op, const void *x_in) {
     const T *units = (const T *)s->d_units;
-    const T *X = (const T *)s->d_X;
+    const T *X = (const T *)x_in;
     // row partials are indexed by local unit; the buffer starts at the rank's first tile
     T *rowpart = (T *)s->d_part +
                  (s->u_begin - s->t_first * s->L.units_per_tile) * (3 * s->L.rows_per_unit);
     T *colpart = (T *)s->d_part + s->rowpart_elems;
     const dim3 grid(s->n_waves / 4), block(256);
-    if (s->nontemporal)
-        hipLaunchKernelGGL((stress_grad_kernel<T, true>), grid, block, 0, s->stream, units, X,
-                           s->d_udesc, s->d_wave_range, s->d_wave_slot, rowpart, colpart,
-                           s->d_stresspart, s->stride);
-    else
-        hipLaunchKernelGGL((stress_grad_kernel<T, false>), grid, block, 0, s->stream, units, X,
-                           s->d_udesc, s->d_wave_range, s->d_wave_slot, rowpart, colpart,
-                           s->d_stresspart, s->stride);
+#define BB_LAUNCH(NTV, OPV)                                                                     \
+    hipLaunchKernelGGL((stress_grad_kernel<T, NTV, OPV>), grid, block, 0, s->stream, units, X, \
+                       s->d_udesc, s->d_wave_range, s->d_wave_slot, rowpart, colpart,          \
+                       s->d_stresspart, s->stride)
+    if (op == kOpMatvec2) {
+        if (s->nontemporal) BB_LAUNCH(true, kOpMatvec2); else BB_LAUNCH(false, kOpMatvec2);
+    } else {
+        if (s->nontemporal) BB_LAUNCH(true, kOpStress); else BB_LAUNCH(false, kOpStress);
+    }
+#undef BB_LAUNCH
     BB_HIP_CHECK(hipGetLastError());
     return BB_OK;
 }
 
 template <typename T>
-int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out) {
+int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, double scale) {
     ReduceParams<T> p;
     p.part = (const T *)s->d_part;
     p.stresspart = s->d_stresspart;
     p.X = (T *)s->d_X;
     p.V = (T *)s->d_V;
     p.mu = (T)s->momentum;
+    p.scale = (T)scale;
     p.exch = (T *)s->d_exch;
     p.part_out = (T *)s->d_part + s->part2_off;
     p.stress_out = stress_out;
@@ -1112,12 +1141,14 @@ int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out) {
     return BB_OK;
 }
 
-int launch_grad(bb_solver *s) {
-    return s->dtype == BB_F32 ? launch_grad_t<float>(s) : launch_grad_t<double>(s);
+int launch_grad(bb_solver *s, int op = kOpStress, const void *x_in = nullptr) {
+    if (!x_in) x_in = s->d_X;
+    return s->dtype == BB_F32 ? launch_grad_t<float>(s, op, x_in)
+                              : launch_grad_t<double>(s, op, x_in);
 }
-int launch_reduce(bb_solver *s, int mode, double lr, double *stress_out) {
-    return s->dtype == BB_F32 ? launch_reduce_t<float>(s, mode, lr, stress_out)
-                              : launch_reduce_t<double>(s, mode, lr, stress_out);
+int launch_reduce(bb_solver *s, int mode, double lr, double *stress_out, double scale = 2.0) {
+    return s->dtype == BB_F32 ? launch_reduce_t<float>(s, mode, lr, stress_out, scale)
+                              : launch_reduce_t<double>(s, mode, lr, stress_out, scale);
 }
 
 hipEvent_t *timing_slot(bb_solver *s) {
@@ -1594,6 +1625,53 @@ int bb_solver_write_exchange(bb_solver *s, const double *host, int64_t n) {
     if (e != hipSuccess)
         return bb::fail(BB_ERR_HIP, std::string("bb_solver_write_exchange: ") + hipGetErrorString(e));
     return BB_OK;
+}
+
+int bb_solver_matvec_sq(bb_solver *s, const double *x, double *y) {
+    BB_REQUIRE(s != nullptr && x != nullptr && y != nullptr, "bb_solver_matvec_sq: NULL argument");
+    if (!s->have_wish) return bb::fail(BB_ERR_STATE, "bb_solver_matvec_sq: no wish distances set");
+    if (s->grad_pending)
+        return bb::fail(BB_ERR_STATE, "bb_solver_matvec_sq: a bb_solver_grad is pending");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    const int64_t n3 = s->L.n_pad * 3, es = bb::elem_size(s->dtype);
+    void *d_in = nullptr;
+    BB_TRY(dev_alloc((char **)&d_in, n3 * es));
+    hipError_t e = hipMemsetAsync(s->d_f64_tmp, 0, (size_t)n3 * 8, s->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(s->d_f64_tmp, x, (size_t)s->L.n_bins * 24, hipMemcpyHostToDevice, s->stream);
+    if (e == hipSuccess) {
+        const unsigned grid = (unsigned)((n3 + 255) / 256);
+        if (s->dtype == BB_F32)
+            hipLaunchKernelGGL(f64_to_T_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
+                               s->d_f64_tmp, (float *)d_in, n3);
+        else
+            hipLaunchKernelGGL(f64_to_T_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
+                               s->d_f64_tmp, (double *)d_in, n3);
+        e = hipGetLastError();
+    }
+    int rc = BB_OK;
+    if (e != hipSuccess) rc = bb::fail(BB_ERR_HIP, std::string("bb_solver_matvec_sq: ") + hipGetErrorString(e));
+    if (rc == BB_OK) rc = launch_grad(s, kOpMatvec2, d_in);
+    if (rc == BB_OK) rc = launch_reduce(s, kReduceExchange, 0.0, nullptr, 1.0);
+    if (rc == BB_OK) {
+        const unsigned grid = (unsigned)((n3 + 255) / 256);
+        if (s->dtype == BB_F32)
+            hipLaunchKernelGGL(T_to_f64_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
+                               (const float *)s->d_exch, s->d_f64_tmp, n3);
+        else
+            hipLaunchKernelGGL(T_to_f64_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
+                               (const double *)s->d_exch, s->d_f64_tmp, n3);
+        e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(y, s->d_f64_tmp, (size_t)s->L.n_bins * 24, hipMemcpyDeviceToHost,
+                               s->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        if (e != hipSuccess)
+            rc = bb::fail(BB_ERR_HIP, std::string("bb_solver_matvec_sq: ") + hipGetErrorString(e));
+    }
+    hipStreamSynchronize(s->stream);
+    hipFree(d_in);
+    return rc;
 }
 
 int bb_solver_stress(bb_solver *s, double *stress) {

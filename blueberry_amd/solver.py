@@ -119,6 +119,14 @@ class HipEngine(object):
     def apply(self, lr):
         _lib.check(self._lib.bb_solver_apply(self._h, float(lr)), "bb_solver_apply")
 
+    def matvec_sq(self, x):
+        """(D o D) @ x for this rank's units; x is (n_bins, 3)."""
+        x = _check_coords(x, self.n_bins)
+        y = numpy.empty_like(x)
+        _lib.check(self._lib.bb_solver_matvec_sq(self._h, _lib.as_f64_ptr(x), _lib.as_f64_ptr(y)),
+                   "bb_solver_matvec_sq")
+        return y
+
     def stress(self):
         out = _lib.c_dbl()
         _lib.check(self._lib.bb_solver_stress(self._h, out), "bb_solver_stress")
@@ -309,6 +317,9 @@ class StructureSolver(object):
         Whether the input matrix holds contact counts or wish distances.
     seed : int
         Seed of the default initial coordinates (numpy default_rng standard normal).
+    init : 'random' or 'spectral'
+        Start used when `fit()` gets no `init=` array: seeded standard normal, or
+        classical MDS computed on the device (`spectral_init`).
     momentum : float in [0, 1)
         Heavy-ball coefficient mu: V <- mu V - lr g, X <- X + V.  0 = plain steps.
     device : int or None
@@ -325,7 +336,8 @@ class StructureSolver(object):
     """
 
     def __init__(self, n_iter=100, lr="auto", dtype="float32", alpha=3.0, kind="counts",
-                 seed=0, device=None, distributed=None, engine=None, momentum=0.0):
+                 seed=0, device=None, distributed=None, engine=None, momentum=0.0,
+                 init="random"):
         if dtype not in _DTYPES:
             raise ValueError("dtype must be 'float32' or 'float64'")
         if kind not in _KINDS:
@@ -339,6 +351,9 @@ class StructureSolver(object):
         if not 0.0 <= float(momentum) < 1.0:
             raise ValueError("momentum must be in [0, 1)")
         self.momentum = float(momentum)
+        if init not in ("random", "spectral"):
+            raise ValueError("init must be 'random' or 'spectral' (or pass init= to fit())")
+        self.init = init
         self.n_iter, self.lr, self.dtype, self.alpha, self.kind, self.seed = (
             int(n_iter), lr, dtype, float(alpha), kind, int(seed))
         self.device, self.distributed = device, distributed
@@ -372,7 +387,7 @@ class StructureSolver(object):
             raise ValueError("need at least 2 bins")
         rank, world = _dist_state(self.distributed)
         lr = 1.0 / (2.0 * n) if self.lr == "auto" else float(self.lr)
-        if init is None:
+        if init is None and self.init == "random":
             init = numpy.random.default_rng(self.seed).standard_normal((n, 3))
 
         tiles = None
@@ -388,6 +403,8 @@ class StructureSolver(object):
                 eng.set_wish_sparse(rows, cols, vals, self.kind, self.alpha, KRnorm, KRexpected)
             else:
                 eng.set_wish_dense(matrix, self.kind, self.alpha)
+            if init is None:                       # 'spectral': needs the resident matrix
+                init = spectral_init(eng, n, world, seed=self.seed)
             eng.set_coords(init)
             if self.momentum:
                 eng.set_momentum(self.momentum)
@@ -424,6 +441,38 @@ class StructureSolver(object):
     def fit_transform(self, X, init=None):
         """`fit(X)` and return the (n_bins, 3) coordinates."""
         return self.fit(X, init=init).structure_
+
+
+def spectral_init(eng, n, world, n_iter=40, seed=0):
+    """Classical-MDS start: the top three eigenpairs of B = -1/2 J (D o D) J,
+    J = I - 11'/n, by block power iteration with a Rayleigh-Ritz step, using the
+    device matvec over the resident units (`bb_solver_matvec_sq`); X0 = V sqrt(L).
+    Exact (up to a rigid motion) for a complete, noise-free distance matrix; for
+    incomplete maps the missing pairs count as zero distance, so it is a start,
+    not a solution.  Plays the part SURVEY.md 8(f)-2 assigns to the reference's
+    `ContactMap.eigenvector` (`blueberry/datatypes.pyx:216-235`)."""
+    def apply_B(V):
+        U = V - V.mean(axis=0)
+        W = eng.matvec_sq(U)
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.from_numpy(W)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+                dist.all_reduce(t)
+                W = t.cpu().numpy()
+            else:
+                dist.all_reduce(t)
+        return -0.5 * (W - W.mean(axis=0))
+
+    V = numpy.linalg.qr(numpy.random.default_rng(seed).standard_normal((n, 3)))[0]
+    for _ in range(int(n_iter)):
+        V = numpy.linalg.qr(apply_B(V))[0]
+    Z = apply_B(V)
+    evals, evecs = numpy.linalg.eigh(0.5 * (V.T @ Z + Z.T @ V))       # Rayleigh-Ritz, 3x3
+    order = numpy.argsort(evals)[::-1]
+    return (V @ evecs[:, order]) * numpy.sqrt(numpy.maximum(evals[order], 0.0))
 
 
 def run_iterations(eng, n_iter, lr, world):

@@ -177,6 +177,15 @@ BB_API int bb_solver_set_exchange_buffer(bb_solver *s, void *dev_ptr);
 BB_API int bb_solver_read_exchange(bb_solver *s, double *host, int64_t n);
 BB_API int bb_solver_write_exchange(bb_solver *s, const double *host, int64_t n);
 
+/* Y = (D o D) X for this rank's resident units: y_i = sum_j delta_ij^2 x_j over
+ * the symmetric matrix of squared wish distances (absent pairs count 0), for
+ * three right-hand sides at once; x, y are (n_bins,3) float64 on the host.  One
+ * sweep of the same kernel and layout as the gradient.  With world > 1 the
+ * caller sums y over the ranks.  It is the operator of classical-MDS / spectral
+ * initialisation -- the role SURVEY.md 8(f)-2 gives the reference's
+ * ContactMap.eigenvector (blueberry/datatypes.pyx:216-235). */
+BB_API int bb_solver_matvec_sq(bb_solver *s, const double *x, double *y);
+
 /* Stress of the current coordinates (one gradient pass, no update). */
 BB_API int bb_solver_stress(bb_solver *s, double *stress);
 /* Copies the stress history (one value per completed iteration since the

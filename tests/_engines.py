@@ -76,3 +76,17 @@ class OracleEngine(object):
 
     def stress_history(self):
         return numpy.array(self.hist)
+
+    def matvec_sq(self, x):
+        """(D o D) @ x restricted to the pairs this rank's units own (numpy)."""
+        n, vw, upt = self.n_bins, self.info.vw, self.info.units_per_tile
+        rpu = vw // upt
+        own = numpy.zeros((n, n), dtype=bool)
+        for u in range(self.u_begin, self.u_end):
+            t, sub = divmod(u, upt)
+            i0, j0 = int(self.ti[t]) * vw + sub * rpu, int(self.tj[t]) * vw
+            own[i0:min(i0 + rpu, n), j0:min(j0 + vw, n)] = True
+        own = numpy.triu(own, 1)
+        a = numpy.where(own, self.w * self.w, 0.0)
+        x = numpy.asarray(x, dtype=numpy.float64)
+        return a @ x + a.T @ x

@@ -38,6 +38,10 @@ def _worker(rank, world, port, n, k, dtype, q):
         x0 = _oracle.noisy_init(xs)
         s = bb.StructureSolver(n_iter=k, dtype=dtype, kind="wish", engine=OracleEngine)
         s.fit(w, init=x0)                      # distributed=None: picks up the gloo job
+        # spectral start: the per-rank matvec shares are summed over the ranks
+        sp = bb.StructureSolver(n_iter=1, dtype=dtype, kind="wish", engine=OracleEngine,
+                                init="spectral").fit(w)
+        assert sp.stress_[0] < 1e-6 * s.stress_[0], (sp.stress_[0], s.stress_[0])
 
         r = _oracle.golden("band_count")["in_gappy_n1000"]
         a, b = band_row_share(r.shape[0], rank, world)

@@ -524,3 +524,38 @@ def test_solver_momentum_matches_oracle(oracle, mu):
     e.close()
     with pytest.raises(ValueError):
         bb.StructureSolver(momentum=1.0)
+
+
+# ---- spectral initialisation ------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-12), ("float32", 1e-5)])
+def test_matvec_sq_matches_numpy(dtype, tol):
+    n = 1100
+    xs, w, _ = _problem(n)
+    w[3, :] = w[:, 3] = 0.0                                 # an unconstrained bin
+    x = numpy.random.default_rng(2).standard_normal((n, 3))
+    want = (w * w) @ x
+    for world in (1, 3):
+        got = numpy.zeros_like(x)
+        for rank in range(world):
+            e = HipEngine(n, dtype, rank=rank, world=world)
+            e.set_wish_dense(w, "wish", 3.0)
+            got += e.matvec_sq(x)
+            e.close()
+        assert numpy.abs(got - want).max() < tol * numpy.abs(want).max(), (dtype, world)
+
+
+def test_spectral_init_recovers_exact_distances():
+    """Classical MDS is exact for a complete noise-free distance matrix: the
+    stress at the spectral start is ~0 against ~1e5 at the random start, and the
+    solver stays there."""
+    n = 1500
+    xs, w, _ = _problem(n)
+    rnd = bb.StructureSolver(n_iter=1, dtype="float64", kind="wish", init="random").fit(w)
+    spc = bb.StructureSolver(n_iter=3, dtype="float64", kind="wish", init="spectral").fit(w)
+    assert spc.stress_[0] < 1e-6 * rnd.stress_[0]
+    assert spc.stress_[-1] <= spc.stress_[0] * 1.0000001
+    # same up to a rigid motion: pairwise distances agree
+    d = _oracle.wish_from_coords(spc.structure_)
+    assert numpy.abs(d - w).max() < 1e-3 * w.max()
+    with pytest.raises(ValueError):
+        bb.StructureSolver(init="pca")

@@ -148,6 +148,18 @@ def test_solver_with_injected_engine_single_rank(oracle):
                              .fit_transform(w), s.structure_)
 
 
+def test_spectral_init_host_loop_is_classical_mds():
+    from tests._engines import OracleEngine
+    from tests import _oracle
+    n = 200
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    s = bb.StructureSolver(n_iter=1, dtype="float64", kind="wish", init="spectral",
+                           distributed=False, engine=OracleEngine).fit(w)
+    assert numpy.abs(_oracle.wish_from_coords(s.structure_) - w).max() < 1e-6 * w.max()
+    assert s.stress_[0] < 1e-10 * (w ** 2).sum()
+
+
 def test_count_band_regions_input_checks():
     with pytest.raises(ValueError):
         bb.band._as_regions(numpy.zeros((2, 2)))
