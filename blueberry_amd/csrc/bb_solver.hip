@@ -145,11 +145,6 @@ typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kDropOffset = 0x80000000u;
 
-__device__ __forceinline__ void store_row3(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, float a,
-                                           float b, float c) {
-    u32x3 v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c)};
-    __builtin_amdgcn_raw_buffer_store_b96(v, rsrc, voff, 0, 0);
-}
 __device__ __forceinline__ void store_row3(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, double a,
                                            double b, double c) {
     u32x4 v = {(unsigned)__double2loint(a), (unsigned)__double2hiint(a),
