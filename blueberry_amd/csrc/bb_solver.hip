@@ -444,10 +444,8 @@ __device__ __forceinline__ void store_strip(const T (&gc)[Traits<T>::VPL][3],
     }
 }
 
-// `stride` consecutive waves share one contiguous chunk of units and take its
-// units round-robin (wave k of the group: first+k, first+k+stride, ...), so the
-// group streams one contiguous window of HBM together; 4 independent waves per
-// workgroup.  No LDS, no barriers, no atomics: results are bitwise reproducible.
+// One wave = one contiguous chunk of units; 4 independent waves per workgroup.
+// No LDS, no barriers, no atomics: results are bitwise reproducible.
 //
 // Arguments are separate __restrict__ pointers (not a struct) so that the
 // read-only index arrays are provably unclobbered and load through the scalar
@@ -464,8 +462,7 @@ template <typename T, bool NT, int OP>
 __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
     const T *__restrict__ units, const T *__restrict__ X, const int2 *__restrict__ udesc,
     const int2 *__restrict__ wave_range, const int32_t *__restrict__ wave_slot,
-    T *__restrict__ rowpart, T *__restrict__ colpart, double *__restrict__ stresspart,
-    int stride) {
+    T *__restrict__ rowpart, T *__restrict__ colpart, double *__restrict__ stresspart) {
     using Vec = typename Traits<T>::Vec;
     constexpr int VPL = Traits<T>::VPL;
     constexpr int VW = Traits<T>::VW;
@@ -499,7 +496,7 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
         };
 
         int2 dc = udesc[ua];                                   // current unit
-        int2 dn = udesc[ua + stride < ub ? ua + stride : ua];  // next unit
+        int2 dn = udesc[ua + 1 < ub ? ua + 1 : ua];            // next unit
         // Prologue: the x rows of the first unit, then its 8 matrix rows.
         // Row coordinates of a unit.  fp32: 12 wave-uniform scalars fetched through
         // the scalar cache (X is read-only in this kernel), one unit ahead -- no
@@ -537,9 +534,9 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
 
         auto unit_step = [&](int u) __attribute__((always_inline)) {
             // the wave's last unit "prefetches" itself: harmless, stays in bounds
-            const int un = u + stride < ub ? u + stride : u;
+            const int un = u + 1 < ub ? u + 1 : u;
             const XRow xrn = xrow_load(dn.x);
-            const int2 dnn = udesc[un + stride < ub ? un + stride : un];
+            const int2 dnn = udesc[un + 1 < ub ? un + 1 : un];
             unsigned row_voff;
             if constexpr (sizeof(T) == 4)   // fp32: lanes 48..59 store one of the 12 sums each
                 row_voff = (lane >= 48 && lane < 60)
@@ -578,10 +575,10 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
             const int curj = dc.y;
             strip_load(curj);
             unit_step(u);
-            u += stride;
+            ++u;
             while (u < ub && dc.y == curj) {
                 unit_step(u);
-                u += stride;
+                ++u;
             }
             strip_store(slot);
             ++slot;
@@ -815,7 +812,6 @@ __global__ __launch_bounds__(256) void gen_units_kernel(const double *__restrict
 template <bool NT>
 __global__ __launch_bounds__(256, 4) void stream_read_kernel(const float4 *__restrict__ units,
                                                              const int2 *__restrict__ wave_range,
-                                                             int stride,
                                                              float *__restrict__ sink) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -826,8 +822,8 @@ __global__ __launch_bounds__(256, 4) void stream_read_kernel(const float4 *__res
         const float4 *first = units + (int64_t)ua * 512 + lane;
 #pragma unroll
         for (int r = 0; r < 8; ++r) d[r] = stream_load<NT>(first + r * 64);
-        for (int u = ua; u < ub; u += stride) {
-            const int un = u + stride < ub ? u + stride : u;
+        for (int u = ua; u < ub; ++u) {
+            const int un = u + 1 < ub ? u + 1 : u;
             const float4 *next = units + (int64_t)un * 512 + lane;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -872,7 +868,6 @@ struct bb_solver {
     bool own_exch = false;
     int2 *d_udesc = nullptr;
     int2 *d_wave_range = nullptr;
-    int stride = 1;
     bool nontemporal = true;
     int32_t *d_wave_slot = nullptr;
     double *d_stresspart = nullptr;
@@ -912,16 +907,6 @@ int dev_alloc(T **p, int64_t count) {
         if (_rc != BB_OK) return _rc; \
     } while (0)
 
-int interleave() {
-    const char *e = getenv("BB_INTERLEAVE");
-    int v = e ? atoi(e) : 1;
-    if (v < 1) v = 1;
-    if (v > 1024) v = 1024;
-    int p2 = 1;
-    while (p2 * 2 <= v) p2 *= 2;
-    return p2;
-}
-
 // Waves per CU (4 waves = one workgroup).  Measured on MI355X (profiles/
 // r01_sweeps.txt): with the rolling 8-KiB window one wave per SIMD already keeps
 // enough bytes in flight, and fewer, longer chunks mean fewer column-partial
@@ -959,35 +944,26 @@ int build_indices(bb_solver *s) {
     nw = bb::round_up(nw, 4);
     s->n_waves = (int)nw;
 
-    // Groups of `stride` waves share a contiguous chunk and interleave its units.
     if (s->n_local >= ((int64_t)1 << 31))
         return bb::fail(BB_ERR_INVALID, "bb_solver_create: more than 2^31 units on one rank");
-    int64_t stride = interleave();
-    while (stride > 1 && nw % stride) stride >>= 1;
-    s->stride = (int)stride;
     {
         // non-temporal matrix loads are the default (measured: +2.5 % on the
         // kernel, +9 % on a pure read sweep); BB_NT=0 turns them off
         const char *e = getenv("BB_NT");
         s->nontemporal = !(e && atoi(e) == 0);
     }
-    const int64_t groups = nw / stride;
+    // wave w owns the contiguous chunk [n_local*w/nw, n_local*(w+1)/nw)
     std::vector<int2> wave_range(nw);
     std::vector<int32_t> wave_slot(nw);
-    for (int64_t g = 0; g < groups; ++g) {
-        const int64_t ga = (int64_t)((__int128)s->n_local * g / groups);
-        const int64_t gb = (int64_t)((__int128)s->n_local * (g + 1) / groups);
-        for (int64_t k = 0; k < stride; ++k) {
-            const int64_t w = g * stride + k;
-            wave_range[w] = make_int2((int)std::min(ga + k, gb), (int)gb);
-        }
-    }
+    for (int64_t w = 0; w < nw; ++w)
+        wave_range[w] = make_int2((int)((__int128)s->n_local * w / nw),
+                                  (int)((__int128)s->n_local * (w + 1) / nw));
     // column-partial slots: one per (wave, strip) intersection, in wave order
     std::vector<int32_t> slot_strip;
     for (int64_t w = 0; w < nw; ++w) {
         wave_slot[w] = (int32_t)slot_strip.size();
         int cur = -1;
-        for (int64_t ul = wave_range[w].x; ul < wave_range[w].y; ul += stride) {
+        for (int64_t ul = wave_range[w].x; ul < wave_range[w].y; ++ul) {
             const int J = s->udesc[ul].y / (int)vw;
             if (J != cur) {
                 slot_strip.push_back(J);
@@ -1094,7 +1070,7 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
 #define BB_LAUNCH(NTV, OPV)                                                                     \
     hipLaunchKernelGGL((stress_grad_kernel<T, NTV, OPV>), grid, block, 0, s->stream, units, X, \
                        s->d_udesc, s->d_wave_range, s->d_wave_slot, rowpart, colpart,          \
-                       s->d_stresspart, s->stride)
+                       s->d_stresspart)
     if (op == kOpMatvec2) {
         if (s->nontemporal) BB_LAUNCH(true, kOpMatvec2); else BB_LAUNCH(false, kOpMatvec2);
     } else {
@@ -1744,11 +1720,11 @@ int bb_solver_measure_stream_read(bb_solver *s, int launches, double *ms_avg) {
     auto launch = [&]() {
         if (s->nontemporal)
             hipLaunchKernelGGL((stream_read_kernel<true>), dim3(s->n_waves / 4), dim3(256), 0,
-                               s->stream, (const float4 *)s->d_units, s->d_wave_range, s->stride,
+                               s->stream, (const float4 *)s->d_units, s->d_wave_range,
                                (float *)s->d_f64_tmp);
         else
             hipLaunchKernelGGL((stream_read_kernel<false>), dim3(s->n_waves / 4), dim3(256), 0,
-                               s->stream, (const float4 *)s->d_units, s->d_wave_range, s->stride,
+                               s->stream, (const float4 *)s->d_units, s->d_wave_range,
                                (float *)s->d_f64_tmp);
     };
     launch();  // warm-up
