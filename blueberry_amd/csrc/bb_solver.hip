@@ -340,14 +340,11 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&x
         pair_step2<0, 0, true, OP>(f32x2{d[2 * r].x, d[2 * r].y}, xi, yi, zi, st, rx, ry, rz, s2);
         pair_step2<0, 1, false, OP>(f32x2{d[2 * r].z, d[2 * r].w}, xi, yi, zi, st, rx, ry, rz, s2);
         d[2 * r] = stream_load<NT>(next + (2 * r) * 64);
-        // three scheduling regions per row (load 0 | load 1 | reduce+store): inside a
-        // region the two halves interleave, which hides the 1-wait-state hazard
-        // between dependent v_pk_* ops that costs an s_nop when they run back to back
-        __builtin_amdgcn_sched_barrier(0);
+        // (no sched_barrier here: letting the scheduler mix the rows of a unit measured
+        // 1 % faster at N=50k and 6 % faster at 1/8 size; it stays within 125 VGPRs)
         pair_step2<1, 0, true, OP>(f32x2{d[2 * r + 1].x, d[2 * r + 1].y}, xi, yi, zi, st, qx, qy, qz, s2);
         pair_step2<1, 1, false, OP>(f32x2{d[2 * r + 1].z, d[2 * r + 1].w}, xi, yi, zi, st, qx, qy, qz, s2);
         d[2 * r + 1] = stream_load<NT>(next + (2 * r + 1) * 64);
-        __builtin_amdgcn_sched_barrier(0);
         rx += qx; ry += qy; rz += qz;
         float gx = rx.x + rx.y, gy = ry.x + ry.y, gz = rz.x + rz.y;
 #ifndef BB_ABL_NODPP
@@ -355,7 +352,6 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&x
 #endif
         const float mine = comp == 0 ? gx : (comp == 1 ? gy : gz);
         keep = (slot >= 3 * r && slot < 3 * r + 3) ? mine : keep;
-        __builtin_amdgcn_sched_barrier(0);
     }
 #ifndef BB_ABL_NOSTORE
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(keep), row_rsrc, row_voff, 0, 0);
