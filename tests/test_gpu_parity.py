@@ -559,3 +559,76 @@ def test_spectral_init_recovers_exact_distances():
     assert numpy.abs(d - w).max() < 1e-3 * w.max()
     with pytest.raises(ValueError):
         bb.StructureSolver(init="pca")
+
+
+# ---- BASELINE config 2 at its full size, directly against the oracle -----------------
+def test_solver_fp32_chr1_10kb_sized_vs_oracle(oracle):
+    """N = 24,926 bins (chr1 at 10 kb), fp32, tol 1e-5 vs the fp64 oracle on the
+    identical matrix.  K = 2 keeps the single-core oracle to a few seconds; the
+    second stress value already depends on every coordinate of the first update."""
+    n, k = 24926, 2
+    xs = _oracle.random_walk(n)
+    w = numpy.empty((n, n))
+    for a in range(0, n, 2000):
+        d = xs[a:a + 2000, None, :] - xs[None, :, :]
+        w[a:a + 2000] = numpy.sqrt((d * d).sum(-1))
+    x0 = _oracle.noisy_init(xs)
+    lr = 1.0 / (2 * n)
+    X_ref, h_ref = oracle.solve(w, x0, k, lr, f64=False)
+    s = bb.StructureSolver(n_iter=k, lr=lr, dtype="float32", kind="wish").fit(w, init=x0)
+    assert numpy.abs(s.stress_ / h_ref - 1).max() < 1e-5
+    assert _rel(s.structure_, X_ref) < 1e-5
+
+
+# ---- API state behaviour -----------------------------------------------------------------
+def test_solver_state_machine():
+    n = 300
+    xs, w, x0 = _problem(n)
+    s0 = bb.StructureSolver(n_iter=0, dtype="float64", kind="wish").fit(w, init=x0)
+    assert numpy.array_equal(s0.structure_, x0) and s0.stress_.shape == (0,)
+    e = HipEngine(n, "float64")
+    e.set_wish_dense(w, "wish", 3.0)
+    e.set_coords(x0)
+    s_a = e.stress()
+    assert e.stress() == s_a and e.stress_history().shape == (0,)     # no side effects
+    assert numpy.array_equal(e.get_coords(), x0)
+    e.iterate(3, 1.0 / (2 * n))
+    h = e.stress_history()
+    assert h.shape == (3,) and h[0] == s_a
+    with pytest.raises(RuntimeError):
+        e.apply(0.1)                                  # no grad pending
+    e.grad()
+    with pytest.raises(RuntimeError):
+        e.matvec_sq(x0)                               # would clobber the pending exchange buffer
+    e.apply(1.0 / (2 * n))
+    assert e.stress_history().shape == (4,)
+    e.set_coords(x0)                                  # resets history (and velocity)
+    assert e.stress_history().shape == (0,)
+    e.close()
+    e.close()                                         # idempotent
+    r = HipEngine(n, "float64", rank=0, world=2)
+    r.set_wish_dense(w, "wish", 3.0)
+    r.set_coords(x0)
+    with pytest.raises(RuntimeError, match="all-reduce"):
+        r.iterate(1, 0.1)                             # world > 1 must go through grad/apply
+    r.close()
+
+
+def test_wish_matrix_with_bad_entries_is_sanitised(oracle):
+    """NaN / inf / negative wish distances mean "no constraint" (SPEC 2.1)."""
+    n = 200
+    xs, w, x0 = _problem(n)
+    bad = w.copy()
+    bad[3, 7] = bad[7, 3] = numpy.nan
+    bad[4, 9] = bad[9, 4] = numpy.inf
+    bad[5, 11] = bad[11, 5] = -2.0
+    clean = w.copy()
+    for i, j in ((3, 7), (4, 9), (5, 11)):
+        clean[i, j] = clean[j, i] = 0.0
+    X_ref, h_ref = oracle.solve(clean, x0, 4, 1.0 / (2 * n))
+    for dtype, tol in (("float64", 1e-12), ("float32", 1e-5)):
+        s = bb.StructureSolver(n_iter=4, dtype=dtype, kind="wish").fit(bad, init=x0)
+        assert numpy.isfinite(s.structure_).all()
+        assert numpy.abs(s.stress_ / h_ref - 1).max() < tol and _rel(s.structure_, X_ref) < tol
+    with pytest.raises(ValueError):
+        bb.StructureSolver(n_iter=1).fit(w, init=numpy.full((n, 3), numpy.nan))
