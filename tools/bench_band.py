@@ -21,3 +21,9 @@ for n, res in ((20000, 5000), (50000, 5000), (309568, 10000)):
         assert c == g
         line += "; CPU oracle 1 core %.2f s = %.2f Gpair/s; x%.0f" % (tc, pairs / tc / 1e9, tc / tg)
     print(line)
+r = numpy.arange(1000) * 50000.0
+t0 = time.perf_counter()
+for _ in range(200):
+    bb.count_band_regions(r)
+print("N=1000 (chr21 @ 50 kb): %.1f us per call on the GPU" % ((time.perf_counter() - t0) / 200 * 1e6))
+t0 = time.perf_counter(); o.count_band_regions(r); print("          CPU oracle: %.1f us" % ((time.perf_counter() - t0) * 1e6))
