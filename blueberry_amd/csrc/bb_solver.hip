@@ -183,8 +183,20 @@ __device__ __forceinline__ void pair_step(const typename Traits<T>::Vec &drow, T
         rinv = __builtin_amdgcn_rsqf(d2);
         dist = d2 * rinv;
     } else {
+#ifdef BB_ABL_F64_LIBM        // timing experiment: library sqrt + IEEE divide (~55 fp64 ops)
         dist = sqrt(d2);
         rinv = 1.0 / dist;
+#else
+        // v_rsq_f64 seed, two Newton steps on 1/sqrt, one on sqrt: ~12 fp64 ops,
+        // both results within 1-2 ulp (the parity tolerance is 1e-12)
+        T r = __builtin_amdgcn_rsq(d2);
+        const T h = T(0.5) * d2;
+        r = r * fma(-h * r, r, T(1.5));
+        r = r * fma(-h * r, r, T(1.5));
+        dist = d2 * r;
+        dist = fma(T(0.5) * r, fma(-dist, dist, d2), dist);
+        rinv = r;
+#endif
     }
     const T res = delta > T(0) ? dist - delta : T(0);
     s = fma(res, res, s);
