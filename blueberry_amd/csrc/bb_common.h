@@ -40,4 +40,14 @@ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 // Select the device, failing loudly when there is none.
 int use_device(int device);
 
+// A device allocation that frees itself (host-staged entry points).
+struct DevBuf {
+    void *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+
 }  // namespace bb

@@ -84,12 +84,6 @@ __global__ void scatter_store_kernel(const double *__restrict__ tr, int64_t n, d
     if (winner[(int64_t)k * d + j] == (int)t) m[(int64_t)k * d + j] = c;
 }
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-};
-
 }  // namespace
 
 extern "C" {
@@ -102,7 +96,7 @@ int bb_contactmap_scatter(const double *triples, int64_t n, int32_t resolution, 
     BB_REQUIRE(resolution != 0, "bb_contactmap_scatter: resolution is 0");
     int rc = bb::use_device(device);
     if (rc != BB_OK) return rc;
-    DevBuf tr, win, m, bad;
+    bb::DevBuf tr, win, m, bad;
     hipStream_t st = nullptr;
     hipError_t e = tr.alloc((size_t)n * 3 * sizeof(double));
     if (e == hipSuccess) e = win.alloc((size_t)d * d * sizeof(int));
@@ -148,7 +142,7 @@ int bb_contactmap_normalize(double *matrix, int64_t n_bins, const double *KRnorm
     int rc = bb::use_device(device);
     if (rc != BB_OK) return rc;
     const int64_t d = n_bins + 1;
-    DevBuf in, out, kr, ke;
+    bb::DevBuf in, out, kr, ke;
     hipStream_t st = nullptr;
     hipError_t e = in.alloc((size_t)d * d * sizeof(double));
     if (e == hipSuccess) e = out.alloc((size_t)d * d * sizeof(double));

@@ -103,12 +103,6 @@ __global__ __launch_bounds__(256) void downsample_kernel(const float *__restrict
     yp5i[i * n5 + j] = m;
 }
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-};
-
 }  // namespace
 
 extern "C" {
@@ -123,7 +117,7 @@ int bb_benjamini_hochberg(const double *p_values, int64_t d, int64_t n, double *
     if (d == 0) return BB_OK;
     const int64_t per_block = (int64_t)kScanBlock * kItems;
     const int64_t nblocks = (d + per_block - 1) / per_block;
-    DevBuf p, q, bm;
+    bb::DevBuf p, q, bm;
     hipStream_t st = nullptr;
     hipError_t e = p.alloc((size_t)d * 8);
     if (e == hipSuccess) e = q.alloc((size_t)d * 8);
@@ -157,7 +151,7 @@ int bb_downsample(const float *yp1, int64_t n1, float *yp5i, int64_t n5, int dev
     int rc = bb::use_device(device);
     if (rc != BB_OK) return rc;
     if (n5 < 2) return BB_OK;
-    DevBuf a, b;
+    bb::DevBuf a, b;
     hipStream_t st = nullptr;
     hipError_t e = a.alloc((size_t)n1 * n1 * 4);
     if (e == hipSuccess) e = b.alloc((size_t)n5 * n5 * 4);

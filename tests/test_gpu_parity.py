@@ -632,3 +632,21 @@ def test_wish_matrix_with_bad_entries_is_sanitised(oracle):
         assert numpy.abs(s.stress_ / h_ref - 1).max() < tol and _rel(s.structure_, X_ref) < tol
     with pytest.raises(ValueError):
         bb.StructureSolver(n_iter=1).fit(w, init=numpy.full((n, 3), numpy.nan))
+
+
+def test_fithic_output_feeds_the_solver(oracle):
+    """Fit-Hi-C output (golden map captured from the reference class) -> to_sparse
+    -> StructureSolver: same as the oracle on the dense matrix the reference's
+    to_matrix builds (symmetrised)."""
+    z = _oracle.golden("fithic_map")
+    res, n_bins = int(z["fh_resolution"]), int(z["fh_n_bins"])
+    fm = bb.FithicContactMap.from_array(z["fh_map"], res)
+    dense = z["fh_matrix_count"]
+    dense = numpy.maximum(dense, dense.T)                # one triangle -> symmetric
+    wish = oracle.counts_to_wish(dense, 3.0)
+    n = n_bins + 1
+    x0 = numpy.random.default_rng(0).standard_normal((n, 3))
+    X_ref, h_ref = oracle.solve(wish, x0, 6, 1.0 / (2 * n))
+    s = bb.StructureSolver(n_iter=6, dtype="float64", lr=1.0 / (2 * n))
+    s.fit(fm.to_sparse("count", n_bins=n_bins), init=x0)
+    assert numpy.abs(s.stress_ / h_ref - 1).max() < 1e-12 and _rel(s.structure_, X_ref) < 1e-12
