@@ -317,6 +317,10 @@ class StructureSolver(object):
         Whether the input matrix holds contact counts or wish distances.
     seed : int
         Seed of the default initial coordinates (numpy default_rng standard normal).
+    tol : float or None
+        None: exactly n_iter steps.  Otherwise stop as soon as the relative stress
+        decrease of one step is <= tol, checked every `check_every` steps (n_iter is
+        then the maximum); `n_iter_` tells how many were run.
     init : 'random' or 'spectral'
         Start used when `fit()` gets no `init=` array: seeded standard normal, or
         classical MDS computed on the device (`spectral_init`).
@@ -337,7 +341,7 @@ class StructureSolver(object):
 
     def __init__(self, n_iter=100, lr="auto", dtype="float32", alpha=3.0, kind="counts",
                  seed=0, device=None, distributed=None, engine=None, momentum=0.0,
-                 init="random"):
+                 init="random", tol=None, check_every=10):
         if dtype not in _DTYPES:
             raise ValueError("dtype must be 'float32' or 'float64'")
         if kind not in _KINDS:
@@ -351,6 +355,11 @@ class StructureSolver(object):
         if not 0.0 <= float(momentum) < 1.0:
             raise ValueError("momentum must be in [0, 1)")
         self.momentum = float(momentum)
+        if tol is not None and not float(tol) > 0:
+            raise ValueError("tol must be positive or None")
+        if int(check_every) < 1:
+            raise ValueError("check_every must be >= 1")
+        self.tol, self.check_every = (None if tol is None else float(tol)), int(check_every)
         if init not in ("random", "spectral"):
             raise ValueError("init must be 'random' or 'spectral' (or pass init= to fit())")
         self.init = init
@@ -408,12 +417,27 @@ class StructureSolver(object):
             eng.set_coords(init)
             if self.momentum:
                 eng.set_momentum(self.momentum)
-            run_iterations(eng, self.n_iter, lr, world)
+            if self.tol is None:
+                run_iterations(eng, self.n_iter, lr, world)
+            else:
+                # early stop: every `check_every` steps the stress history is read
+                # back (one sync) and the loop ends once the relative decrease per
+                # step falls below tol.  Every rank sees the same all-reduced
+                # stress, so all ranks stop at the same iteration.
+                done = 0
+                while done < self.n_iter:
+                    k = min(self.check_every, self.n_iter - done)
+                    run_iterations(eng, k, lr, world)
+                    done += k
+                    h = eng.stress_history()
+                    if h.size >= 2 and h[-2] > 0 and \
+                            abs(h[-2] - h[-1]) <= self.tol * h[-2]:
+                        break
             self.structure_ = eng.get_coords()
             self.stress_ = eng.stress_history()
         finally:
             eng.close()
-        self.n_bins_, self.lr_ = n, lr
+        self.n_bins_, self.lr_, self.n_iter_ = n, lr, int(self.stress_.shape[0])
         return self
 
     def fit_triples(self, triples, resolution, n_bins, KRnorm=None, KRexpected=None, init=None):

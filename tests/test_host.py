@@ -261,3 +261,19 @@ def test_fithic_decimate_py2_semantics():
     # (int + 5000) // 5000 * 5000 - 2500: 500 -> 2500, 1500 -> 2500, 6500/7500 -> 7500, 11500 -> 12500
     want = numpy.array([[2500.0, 7500.0, 7.0, 0.1 * 0.2, 0.3], [2500.0, 12500.0, 5.0, 0.5, 1.0]])
     assert numpy.allclose(fm.map, want) and numpy.array_equal(fm.regions, [2500.0, 7500.0, 12500.0])
+
+
+def test_early_stop_with_tolerance():
+    from tests._engines import OracleEngine
+    from tests import _oracle
+    n = 120
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    kw = dict(dtype="float64", kind="wish", distributed=False, engine=OracleEngine)
+    full = bb.StructureSolver(n_iter=200, **kw).fit(w, init=_oracle.noisy_init(xs))
+    early = bb.StructureSolver(n_iter=200, tol=1e-3, check_every=5, **kw).fit(
+        w, init=_oracle.noisy_init(xs))
+    assert full.n_iter_ == 200 and 5 <= early.n_iter_ < 200 and early.n_iter_ % 5 == 0
+    assert numpy.array_equal(early.stress_, full.stress_[:early.n_iter_])
+    with pytest.raises(ValueError):
+        bb.StructureSolver(tol=0)
