@@ -135,7 +135,7 @@ def main():
             dist.all_reduce(warm)             # creates the communicator now
             torch.cuda.synchronize()
 
-    from blueberry_amd.solver import HipEngine, allreduce_exchange
+    from blueberry_amd.solver import HipEngine, run_iterations
 
     n = a.bins
     xs = random_walk(n, 0)
@@ -144,16 +144,11 @@ def main():
     eng = HipEngine(n, a.dtype, rank=rank, world=world, device=local_rank)
     eng.set_wish_from_coords(xs)          # delta_ij = |x*_i - x*_j| generated in HBM
     eng.set_coords(x0)
-    exch = eng.exchange_tensor() if use_dist else None
-
     def steps(k):
-        if not use_dist:
-            eng.iterate(k, lr)
-        else:
-            for _ in range(k):
-                eng.grad()
-                allreduce_exchange(exch)
-                eng.apply(lr)
+        # world 1: one C call enqueues k fused iterations.  world > 1: grad ->
+        # all-reduce -> apply per iteration, through the library's own RCCL
+        # communicator when it can be made (else torch.distributed's all-reduce)
+        run_iterations(eng, k, lr, 2 if use_dist else 1)
 
     def fence():
         eng.sync()
@@ -177,6 +172,8 @@ def main():
 
     hist = eng.stress_history()
     traffic = eng.traffic()
+    eng_comm = {"rccl": "library-owned RCCL communicator", "torch": "torch.distributed (RCCL)",
+                None: "none"}[eng._comm_state]
 
     # BASELINE metric, second half: wall-clock from a resident matrix and the
     # noisy start X0 to S_k / S_0 <= 1e-3 (the synthetic matrix has a zero-stress
@@ -232,8 +229,8 @@ def main():
                                    "walk, upper triangle packed in HBM, %s; one stress+gradient+"
                                    "update iteration per step" % (n, a.dtype),
                        "bins": n, "pairs_per_step": pairs,
-                       "parallelism": "unit-range sharding x%d + all-reduce(3*n_pad+2)" % world
-                       if world > 1 else "1 gpu"},
+                       "parallelism": "unit-range sharding x%d + all-reduce(3*n_pad+2) via %s"
+                                      % (world, eng_comm) if world > 1 else "1 gpu"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(n, a.dtype, world),

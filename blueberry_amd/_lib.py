@@ -55,6 +55,10 @@ SIGNATURES = {
     "bb_solver_iterate": (c_int, [c_void_p, c_i64, c_dbl]),
     "bb_solver_grad": (c_int, [c_void_p]),
     "bb_solver_apply": (c_int, [c_void_p, c_dbl]),
+    "bb_comm_unique_id": (c_int, [c_void_p]),
+    "bb_solver_comm_init": (c_int, [c_void_p, c_void_p]),
+    "bb_solver_allreduce": (c_int, [c_void_p]),
+    "bb_solver_iterate_dist": (c_int, [c_void_p, c_i64, c_dbl]),
     "bb_solver_exchange_size": (c_int, [c_void_p, p_i64]),
     "bb_solver_get_exchange_buffer": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "bb_solver_set_exchange_buffer": (c_int, [c_void_p, c_void_p]),

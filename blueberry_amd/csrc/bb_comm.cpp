@@ -1,0 +1,31 @@
+// bb_comm.cpp -- run-time binding of RCCL (see bb_comm.h).
+#include "bb_comm.h"
+
+#include <dlfcn.h>
+
+#include <mutex>
+
+namespace bb {
+
+const Rccl &rccl() {
+    static Rccl table;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // RTLD_NOLOAD first: reuse the image the process already has (torch's)
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        table.GetUniqueId = (decltype(table.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        table.CommInitRank = (decltype(table.CommInitRank))dlsym(h, "ncclCommInitRank");
+        table.CommDestroy = (decltype(table.CommDestroy))dlsym(h, "ncclCommDestroy");
+        table.AllReduce = (decltype(table.AllReduce))dlsym(h, "ncclAllReduce");
+        table.GetErrorString = (decltype(table.GetErrorString))dlsym(h, "ncclGetErrorString");
+        table.ok = table.GetUniqueId && table.CommInitRank && table.CommDestroy &&
+                   table.AllReduce && table.GetErrorString;
+    });
+    return table;
+}
+
+}  // namespace bb

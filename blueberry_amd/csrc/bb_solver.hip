@@ -15,11 +15,13 @@
 // cross-lane traffic), and only the row side needs one DPP wave reduction per
 // matrix row -- amortised over 8 pairs per lane in fp32.
 #include <math.h>
+#include <string.h>
 
 #include <algorithm>
 #include <type_traits>
 #include <vector>
 
+#include "bb_comm.h"
 #include "bb_common.h"
 
 namespace {
@@ -889,6 +891,8 @@ struct bb_solver {
     int64_t hist_cap = 0, hist_n = 0;
     bool have_wish = false, have_coords = false, grad_pending = false;
 
+    bb::Rccl::Comm comm = nullptr;  // direct RCCL path (bb_solver_comm_init), else null
+
     bool timing = false;
     std::vector<hipEvent_t> ev;  // triples: start, after grad, after reduce
     size_t ev_used = 0;
@@ -1265,6 +1269,7 @@ int bb_solver_destroy(bb_solver *s) {
     if (!s) return BB_OK;
     hipSetDevice(s->device);
     if (s->stream || !s->own_stream) hipStreamSynchronize(s->stream);
+    if (s->comm) bb::rccl().CommDestroy(s->comm);
     for (hipEvent_t e : s->ev) hipEventDestroy(e);
     hipFree(s->d_units);
     hipFree(s->d_X);
@@ -1533,6 +1538,64 @@ int bb_solver_apply(bb_solver *s, double lr) {
     BB_HIP_CHECK(hipGetLastError());
     s->hist_n++;
     s->grad_pending = false;
+    return BB_OK;
+}
+
+int bb_comm_unique_id(void *id_out) {
+    BB_REQUIRE(id_out != nullptr, "bb_comm_unique_id: id_out is NULL");
+    const bb::Rccl &R = bb::rccl();
+    if (!R.ok) return bb::fail(BB_ERR_HIP, "bb_comm_unique_id: librccl is not loadable");
+    bb::Rccl::UniqueId id;
+    const int rc = R.GetUniqueId(&id);
+    if (rc != bb::Rccl::kSuccess)
+        return bb::fail(BB_ERR_HIP, std::string("ncclGetUniqueId: ") + R.GetErrorString(rc));
+    memcpy(id_out, id.internal, bb::kUniqueIdBytes);
+    return BB_OK;
+}
+
+int bb_solver_comm_init(bb_solver *s, const void *unique_id) {
+    BB_REQUIRE(s != nullptr && unique_id != nullptr, "bb_solver_comm_init: NULL argument");
+    if (s->comm) return bb::fail(BB_ERR_STATE, "bb_solver_comm_init: communicator already made");
+    const bb::Rccl &R = bb::rccl();
+    if (!R.ok) return bb::fail(BB_ERR_HIP, "bb_solver_comm_init: librccl is not loadable");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    bb::Rccl::UniqueId id;
+    memcpy(id.internal, unique_id, bb::kUniqueIdBytes);
+    const int rc = R.CommInitRank(&s->comm, s->world, id, s->rank);
+    if (rc != bb::Rccl::kSuccess) {
+        s->comm = nullptr;
+        return bb::fail(BB_ERR_HIP, std::string("ncclCommInitRank: ") + R.GetErrorString(rc));
+    }
+    return BB_OK;
+}
+
+namespace {
+int enqueue_allreduce(bb_solver *s) {
+    const bb::Rccl &R = bb::rccl();
+    const int rc = R.AllReduce(s->d_exch, s->d_exch, (size_t)(3 * s->L.n_pad + 2),
+                               s->dtype == BB_F32 ? bb::Rccl::kFloat32 : bb::Rccl::kFloat64,
+                               bb::Rccl::kSum, s->comm, s->stream);
+    if (rc != bb::Rccl::kSuccess)
+        return bb::fail(BB_ERR_HIP, std::string("ncclAllReduce: ") + R.GetErrorString(rc));
+    return BB_OK;
+}
+}  // namespace
+
+int bb_solver_allreduce(bb_solver *s) {
+    BB_REQUIRE(s != nullptr, "bb_solver_allreduce: solver is NULL");
+    if (!s->comm) return bb::fail(BB_ERR_STATE, "bb_solver_allreduce: no communicator");
+    if (!s->grad_pending) return bb::fail(BB_ERR_STATE, "bb_solver_allreduce: no bb_solver_grad pending");
+    BB_HIP_CHECK(hipSetDevice(s->device));
+    return enqueue_allreduce(s);
+}
+
+int bb_solver_iterate_dist(bb_solver *s, int64_t iters, double lr) {
+    BB_REQUIRE(iters >= 0, "bb_solver_iterate_dist: iters < 0");
+    for (int64_t k = 0; k < iters; ++k) {
+        BB_TRY(bb_solver_grad(s));
+        BB_TRY(bb_solver_allreduce(s));
+        BB_TRY(bb_solver_apply(s, lr));
+    }
     return BB_OK;
 }
 

@@ -42,6 +42,7 @@ class HipEngine(object):
             None if ti is None else ti.ctypes.data_as(_lib.p_i32),
             None if tj is None else tj.ctypes.data_as(_lib.p_i32), nt), "bb_solver_create")
         self._exch = None
+        self._comm_state = None     # "rccl" | "torch" once the multi-rank path is chosen
 
     # -- lifetime ---------------------------------------------------------
     def close(self):
@@ -163,6 +164,35 @@ class HipEngine(object):
                    "bb_solver_write_exchange")
 
     # -- the all-reduce boundary (world > 1) --------------------------------
+    def comm_setup(self):
+        """Make the library's own RCCL communicator for this job: rank 0 draws the
+        128-byte id, torch.distributed only carries it to the other ranks, every
+        rank joins (`ncclCommInitRank`).  Collective.  Returns False -- on every
+        rank alike -- when RCCL cannot be used, so that the caller can fall back
+        to the torch.distributed all-reduce."""
+        import ctypes
+        import torch.distributed as dist
+        box = [None]
+        if self.rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            if self._lib.bb_comm_unique_id(buf) == _lib.BB_OK:
+                box[0] = buf.raw
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            return False
+        ok = self._lib.bb_solver_comm_init(self._h, box[0]) == _lib.BB_OK
+        # all ranks must take the same path: agree on the outcome
+        import torch
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                            device=torch.device("cuda", self.device))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    def iterate_dist(self, iters, lr):
+        """`iters` x { grad, RCCL all-reduce, apply }, all enqueued by one C call."""
+        _lib.check(self._lib.bb_solver_iterate_dist(self._h, int(iters), float(lr)),
+                   "bb_solver_iterate_dist")
+
     def exchange_tensor(self):
         """A torch tensor aliasing the exchange buffer [g (n_pad,3) | hi | lo].
 
@@ -510,6 +540,14 @@ def run_iterations(eng, n_iter, lr, world):
         return
     import torch.distributed as dist
     if dist.get_backend() == "nccl":
+        if not getattr(eng, "_comm_state", None):
+            # first choice: the library's own RCCL communicator (no framework in the
+            # loop); BB_COMM=torch forces the torch.distributed all-reduce instead
+            direct = os.environ.get("BB_COMM", "rccl") != "torch" and hasattr(eng, "comm_setup")
+            eng._comm_state = "rccl" if (direct and eng.comm_setup()) else "torch"
+        if eng._comm_state == "rccl":
+            eng.iterate_dist(n_iter, lr)
+            return
         t = eng.exchange_tensor()
         for _ in range(n_iter):
             eng.grad()

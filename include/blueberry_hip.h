@@ -171,6 +171,19 @@ BB_API int bb_solver_apply(bb_solver *s, double lr);
 BB_API int bb_solver_exchange_size(const bb_solver *s, int64_t *n_elems);
 BB_API int bb_solver_get_exchange_buffer(bb_solver *s, void **dev_ptr);
 BB_API int bb_solver_set_exchange_buffer(bb_solver *s, void *dev_ptr);
+/* Direct RCCL path: the library loads librccl at run time and owns a
+ * communicator, so the whole multi-rank iteration is enqueued from C on the
+ * solver's own stream -- no framework in the loop.
+ *   bb_comm_unique_id      one rank makes the 128-byte id (ncclGetUniqueId) ...
+ *   bb_solver_comm_init    ... every rank passes it in (ncclCommInitRank; collective)
+ *   bb_solver_allreduce    in-place sum of the exchange buffer, between grad and apply
+ *   bb_solver_iterate_dist `iters` x { grad, allreduce, apply }
+ * The id travels by whatever the caller has (MPI_Bcast, torch.distributed, a file). */
+BB_API int bb_comm_unique_id(void *id_out_128_bytes);
+BB_API int bb_solver_comm_init(bb_solver *s, const void *unique_id_128_bytes);
+BB_API int bb_solver_allreduce(bb_solver *s);
+BB_API int bb_solver_iterate_dist(bb_solver *s, int64_t iters, double lr);
+
 /* Host-staged access to the exchange buffer, widened to float64, for callers
  * whose collective runs on host memory (MPI, gloo): read after bb_solver_grad,
  * sum over ranks, write back, then bb_solver_apply.  n = bb_solver_exchange_size. */

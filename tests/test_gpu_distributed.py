@@ -98,11 +98,15 @@ n, k = 900, 6
 xs = _oracle.random_walk(n); w = _oracle.wish_from_coords(xs); x0 = _oracle.noisy_init(xs)
 lr = 1.0 / (2 * n)
 out = {}
-for name, world in (("fused", 1), ("exchange", 2)):   # world=2 forces grad/all-reduce/apply
+# world=2 forces grad/all-reduce/apply; BB_COMM picks the collective's owner
+for name, world, comm in (("fused", 1, None), ("exchange", 2, "rccl"), ("torch", 2, "torch")):
+    if comm: os.environ["BB_COMM"] = comm
     e = HipEngine(n, "float32")
     e.set_wish_dense(w, "wish", 3.0); e.set_coords(x0)
     run_iterations(e, k, lr, world)
+    assert e._comm_state == comm, (e._comm_state, comm)
     out[name] = (e.get_coords(), e.stress_history()); e.close()
+assert numpy.array_equal(out["torch"][0], out["exchange"][0])      # same kernels, same sums
 assert len(_lib.hip_runtimes_loaded()) == 1, _lib.hip_runtimes_loaded()
 assert numpy.abs(out["fused"][0] - out["exchange"][0]).max() < 1e-5 * numpy.abs(out["fused"][0]).max()
 assert numpy.abs(out["fused"][1] / out["exchange"][1] - 1).max() < 1e-5
