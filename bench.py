@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--cpu-bins", type=int, default=10000)
     ap.add_argument("--cpu-iters", type=int, default=100)
     ap.add_argument("--converge-steps", type=int, default=60)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the multi-rank path with ranks sharing GPUs "
+                         "(host-staged all-reduce); the driver's runs use nccl = RCCL")
     ap.add_argument("--momentum", type=float, default=0.5,
                     help="heavy-ball coefficient of the second time-to-converged-stress leg")
     return ap.parse_args()
@@ -127,11 +130,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         with stdout_to_stderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-            warm = torch.zeros(1, device="cuda")
+            if a.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world,
+                                        device_id=torch.device("cuda", local_rank))
+                warm = torch.zeros(1, device="cuda")
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                warm = torch.zeros(1)
             dist.all_reduce(warm)             # creates the communicator now
             torch.cuda.synchronize()
 
@@ -166,14 +174,15 @@ def main():
     dt = time.perf_counter() - t0
     tim = eng.timing()
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     hist = eng.stress_history()
     traffic = eng.traffic()
     eng_comm = {"rccl": "library-owned RCCL communicator", "torch": "torch.distributed (RCCL)",
-                None: "none"}[eng._comm_state]
+                None: "gloo, host-staged (rehearsal)" if use_dist else "none"}[eng._comm_state]
 
     # BASELINE metric, second half: wall-clock from a resident matrix and the
     # noisy start X0 to S_k / S_0 <= 1e-3 (the synthetic matrix has a zero-stress
