@@ -513,7 +513,7 @@ def spectral_init(eng, n, world, n_iter=40, seed=0):
             import torch.distributed as dist
             t = torch.from_numpy(W)
             if dist.get_backend() == "nccl":
-                t = t.cuda()
+                t = t.to(torch.device("cuda", getattr(eng, "device", 0)))
                 dist.all_reduce(t)
                 W = t.cpu().numpy()
             else:
