@@ -42,7 +42,7 @@ def count_band_regions(regions_ndarray, device=0, distributed=False):
     _lib.check(lib.bb_band_count_rows(_lib.as_f64_ptr(r), n, LOW_FITHIC_CUTOFF,
                                       HIGH_FITHIC_CUTOFF, i_begin, i_end, device, out),
                "bb_band_count_rows")
-    return int(allreduce_count(int(out.value)))
+    return int(allreduce_count(int(out.value), device))
 
 
 def band_row_share(n, rank, world):
@@ -54,10 +54,10 @@ def band_row_share(n, rank, world):
     return i_begin, max(i_begin, i_end)
 
 
-def allreduce_count(local_count):
+def allreduce_count(local_count, device=0):
     import torch
     import torch.distributed as dist
-    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    dev = torch.device("cuda", device) if dist.get_backend() == "nccl" else torch.device("cpu")
     t = torch.tensor([local_count], dtype=torch.int64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
