@@ -650,3 +650,29 @@ def test_fithic_output_feeds_the_solver(oracle):
     s = bb.StructureSolver(n_iter=6, dtype="float64", lr=1.0 / (2 * n))
     s.fit(fm.to_sparse("count", n_bins=n_bins), init=x0)
     assert numpy.abs(s.stress_ / h_ref - 1).max() < 1e-12 and _rel(s.structure_, X_ref) < 1e-12
+
+
+def test_contactmap_file_constructor_matches_reference(tmp_path):
+    """The file-loading constructor (Rao-format RAWobserved / KRnorm / KRexpected,
+    `blueberry/datatypes.pyx:88-120`) on the golden case's files: same matrix,
+    regions, n_bins, filename convention (py2 `resolution/1000`) as the reference."""
+    z = _oracle.golden("contactmap")
+    k, res = 2, int(z["cm2_resolution"])
+    old = (bb.datatypes.RAW_DIR, bb.datatypes.KR_NORM, bb.datatypes.KR_EXP)
+    bb.datatypes.RAW_DIR = str(tmp_path / "{0}_chr{1}_{2}kb.RAWobserved")
+    bb.datatypes.KR_NORM = str(tmp_path / "{0}_chr{1}_{2}kb.KRnorm")
+    bb.datatypes.KR_EXP = str(tmp_path / "{0}_chr{1}_{2}kb.KRexpected")
+    try:
+        tag = ("GM12878_combined", 21, res // 1000)
+        numpy.savetxt(bb.datatypes.RAW_DIR.format(*tag), z["cm2_triples"], delimiter="\t", fmt="%.1f")
+        numpy.savetxt(bb.datatypes.KR_NORM.format(*tag), z["cm2_krnorm"])
+        numpy.savetxt(bb.datatypes.KR_EXP.format(*tag), z["cm2_krexp"])
+        cm = bb.ContactMap("GM12878_combined", 21, res)
+    finally:
+        bb.datatypes.RAW_DIR, bb.datatypes.KR_NORM, bb.datatypes.KR_EXP = old
+    assert cm.n_bins == z["cm2_krnorm"].shape[0] and cm.resolution == res
+    assert cm.filename.endswith("GM12878_combined_chr21_%dkb.RAWobserved" % (res // 1000))
+    assert numpy.array_equal(cm.matrix, z["cm2_matrix_raw"])
+    assert numpy.array_equal(cm.regions, z["cm2_regions"])
+    cm.normalize()
+    assert numpy.array_equal(cm.matrix, z["cm2_matrix_norm"])

@@ -277,3 +277,20 @@ def test_early_stop_with_tolerance():
     assert numpy.array_equal(early.stress_, full.stress_[:early.n_iter_])
     with pytest.raises(ValueError):
         bb.StructureSolver(tol=0)
+
+
+def test_tiles_from_entries_and_plot_smoke():
+    from blueberry_amd.solver import tiles_from_entries
+    ti, tj = tiles_from_entries(1300, [0, 1299, 600, 5], [1299, 0, 700, 5], "float64")
+    # vw = 128: pairs (0,1299)->tile (0,10) once, (600,700)->(4,5), (5,5)->(0,0); order (J, I)
+    assert list(zip(ti.tolist(), tj.tolist())) == [(0, 0), (4, 5), (0, 10)]
+    ti32, tj32 = tiles_from_entries(1300, [0, 1299, 600, 5], [1299, 0, 700, 5], "float32")
+    assert list(zip(ti32.tolist(), tj32.tolist())) == [(0, 0), (1, 1), (0, 2)]
+    with pytest.raises(ValueError):
+        tiles_from_entries(10, [0], [10], "float32")
+    import matplotlib
+    matplotlib.use("Agg")
+    cm = bb.ContactMap.from_matrix(numpy.arange(16.0).reshape(4, 4), resolution=5000,
+                                   celltype="K562", chromosome=3)
+    cm.plot(arcsinh=True)
+    cm.plot(arcsinh=False, cmap="Reds")
