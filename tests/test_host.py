@@ -294,3 +294,19 @@ def test_tiles_from_entries_and_plot_smoke():
                                    celltype="K562", chromosome=3)
     cm.plot(arcsinh=True)
     cm.plot(arcsinh=False, cmap="Reds")
+
+
+def test_bench_cli_contract():
+    """bench.py takes the driver's flags; asking for N>1 without a launcher is an
+    error message, not a hang."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in r.stdout
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "torch.distributed.run" in (r.stderr + r.stdout)
