@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--cpu-bins", type=int, default=10000)
     ap.add_argument("--cpu-iters", type=int, default=100)
     ap.add_argument("--converge-steps", type=int, default=60)
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong (default, what the headline is): the same --bins matrix split "
+                         "over the ranks; weak: bins grow with sqrt(ranks) so that every rank "
+                         "keeps the 1-GPU number of pairs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path with ranks sharing GPUs "
                          "(host-staged all-reduce); the driver's runs use nccl = RCCL")
@@ -145,7 +149,7 @@ def main():
 
     from blueberry_amd.solver import HipEngine, run_iterations
 
-    n = a.bins
+    n = a.bins if a.scaling == "strong" else int(round(a.bins * world ** 0.5))
     xs = random_walk(n, 0)
     x0 = xs + 0.5 * numpy.random.default_rng(1).standard_normal(xs.shape)
     lr = 1.0 / (2 * n)
@@ -230,7 +234,7 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "f32" if a.dtype == "float32" else "f64",
             "data": "synthetic",
