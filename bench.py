@@ -147,7 +147,7 @@ def main():
             dist.all_reduce(warm)             # creates the communicator now
             torch.cuda.synchronize()
 
-    from blueberry_amd.solver import HipEngine, run_iterations
+    from blueberry_amd.solver import HipEngine, run_iterations, select_exchange
 
     n = a.bins if a.scaling == "strong" else int(round(a.bins * world ** 0.5))
     xs = random_walk(n, 0)
@@ -156,10 +156,16 @@ def main():
     eng = HipEngine(n, a.dtype, rank=rank, world=world, device=local_rank)
     eng.set_wish_from_coords(xs)          # delta_ij = |x*_i - x*_j| generated in HBM
     eng.set_coords(x0)
+    if use_dist:
+        # the transport of the per-iteration sum is chosen here, once: the peer
+        # exchange inside the solver's own kernels if it validates against RCCL and
+        # is faster, else the library's RCCL communicator (BB_COMM overrides)
+        with stdout_to_stderr():
+            select_exchange(eng, lr)
+
     def steps(k):
         # world 1: one C call enqueues k fused iterations.  world > 1: grad ->
-        # all-reduce -> apply per iteration, through the library's own RCCL
-        # communicator when it can be made (else torch.distributed's all-reduce)
+        # reduce -> sum over ranks -> update per iteration, also enqueued from C
         run_iterations(eng, k, lr, 2 if use_dist else 1)
 
     def fence():
@@ -185,8 +191,10 @@ def main():
 
     hist = eng.stress_history()
     traffic = eng.traffic()
-    eng_comm = {"rccl": "library-owned RCCL communicator", "torch": "torch.distributed (RCCL)",
-                None: "gloo, host-staged (rehearsal)" if use_dist else "none"}[eng._comm_state]
+    eng_comm = {"peer": "peer exchange (one-shot, in-kernel, IPC arenas over xGMI)",
+                "rccl": "library-owned RCCL communicator", "torch": "torch.distributed (RCCL)",
+                "host": "gloo, host-staged (rehearsal)", None: "none"}[eng._comm_state]
+    comm_trial = eng._comm_trial
 
     # BASELINE metric, second half: wall-clock from a resident matrix and the
     # noisy start X0 to S_k / S_0 <= 1e-3 (the synthetic matrix has a zero-stress
@@ -243,12 +251,16 @@ def main():
                                    "update iteration per step" % (n, a.dtype),
                        "bins": n, "pairs_per_step": pairs,
                        "parallelism": "unit-range sharding x%d + all-reduce(3*n_pad+2) via %s"
-                                      % (world, eng_comm) if world > 1 else "1 gpu"},
+                                      % (world, eng_comm) if world > 1 else "1 gpu",
+                       "exchange": eng._comm_state, "exchange_trial": comm_trial},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(n, a.dtype, world),
                          "kernel": "stress_grad_kernel<%s>" % ("float" if es == 4 else "double"),
                          "kernel_ms": tim["grad_ms"], "reduce_update_ms": tim["reduce_ms"],
+                         # start-to-start of consecutive steps on the device: what is
+                         # left after the two figures above is exchange + update + gaps
+                         "device_step_ms": tim["step_ms"],
                          "timed_launches": tim["launches"],
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "resident_bytes_streamed_per_launch": traffic["unit_bytes"],

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("BB_LIB") or os.path.join(_HERE, "libblueberry_hip.so"
 BB_OK, BB_ERR_INVALID, BB_ERR_HIP, BB_ERR_STATE, BB_ERR_NOMEM = 0, 1, 2, 3, 4
 BB_F32, BB_F64 = 0, 1
 BB_KIND_WISH, BB_KIND_COUNTS = 0, 1
+BB_PEER_HANDLE_BYTES = 128
 
 c_i32, c_i64, c_dbl = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 p_i32, p_i64, p_dbl = (ctypes.POINTER(c_i32), ctypes.POINTER(c_i64), ctypes.POINTER(c_dbl))
@@ -59,6 +60,10 @@ SIGNATURES = {
     "bb_solver_comm_init": (c_int, [c_void_p, c_void_p]),
     "bb_solver_allreduce": (c_int, [c_void_p]),
     "bb_solver_iterate_dist": (c_int, [c_void_p, c_i64, c_dbl]),
+    "bb_solver_peer_export": (c_int, [c_void_p, c_void_p]),
+    "bb_solver_peer_connect": (c_int, [c_void_p, c_void_p]),
+    "bb_solver_iterate_peer": (c_int, [c_void_p, c_i64, c_dbl]),
+    "bb_solver_peer_status": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "bb_solver_exchange_size": (c_int, [c_void_p, p_i64]),
     "bb_solver_get_exchange_buffer": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     "bb_solver_set_exchange_buffer": (c_int, [c_void_p, c_void_p]),
@@ -70,6 +75,7 @@ SIGNATURES = {
     "bb_solver_sync": (c_int, [c_void_p]),
     "bb_solver_set_timing": (c_int, [c_void_p, c_int]),
     "bb_solver_get_timing": (c_int, [c_void_p, p_dbl, p_dbl, p_i64]),
+    "bb_solver_get_step_timing": (c_int, [c_void_p, p_dbl]),
     "bb_solver_measure_stream_read": (c_int, [c_void_p, c_int, p_dbl]),
     "bb_solver_traffic": (c_int, [c_void_p, p_i64, p_i64]),
     "bb_contactmap_scatter": (c_int, [p_dbl, c_i64, c_i32, p_dbl, c_i64, c_int]),

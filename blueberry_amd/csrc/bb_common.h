@@ -39,6 +39,11 @@ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 // Select the device, failing loudly when there is none.
 int use_device(int device);
+// Entry of every call on an existing solver: select its device and drop whatever
+// error an earlier HIP call of this thread left behind (hipGetLastError is
+// per-thread and sticky, and the thread is shared with the caller's other HIP
+// users -- torch, RCCL), so that a launch check reports our launch only.
+int enter_device(int device);
 
 // A device allocation that frees itself (host-staged entry points).
 struct DevBuf {

@@ -15,7 +15,9 @@
 // cross-lane traffic), and only the row side needs one DPP wave reduction per
 // matrix row -- amortised over 8 pairs per lane in fp32.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -611,7 +613,17 @@ enum ReduceMode {
     kReduceApply = 0,      // X -= lr * 2 * sum
     kReduceExchange = 1,   // exch = 2 * sum (+ stress hi/lo)
     kReduceStressOnly = 2, // stress only
-    kReducePartial = 3     // stage 1: raw sum of one slice of a block's chunk list
+    kReducePartial = 3,    // stage 1: raw sum of one slice of a block's chunk list
+    kReducePeer = 4        // 2 * sum (+ stress hi/lo) stored into this rank's slot on every peer
+};
+
+// Peer exchange (bb_solver_peer_*): where this rank's partial goes on each rank
+// (its slot in that rank's receive arena, for one parity) and the flag to raise.
+constexpr int kMaxPeers = 16;
+template <typename T>
+struct PeerTable {
+    T *dst[kMaxPeers];
+    unsigned long long *flag[kMaxPeers];
 };
 
 template <typename T>
@@ -626,6 +638,10 @@ struct ReduceParams {
     T scale;                                 // 2 for the gradient (SPEC 2.3), 1 for a matvec
     T *__restrict__ exch;                    // exchange mode: [3*n_pad | hi | lo]
     T *__restrict__ part_out;                // partial mode: CH elements per workgroup
+    const PeerTable<T> *__restrict__ peer;   // peer mode: destinations, in device memory
+    unsigned *__restrict__ peer_counter;     // peer mode: workgroups done (last one raises flags)
+    unsigned long long seq;                  // peer mode: value the flags take
+    int n_peers;
     double *__restrict__ stress_out;         // apply / stress-only: where the stress goes
     int64_t n_pad;
     int n_waves;
@@ -678,6 +694,8 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
                         const T v = p.mu * p.V[o] - p.lr * g;
                         p.V[o] = v;
                         p.X[o] += v;
+                    } else if (p.mode == kReducePeer) {
+                        for (int q = 0; q < p.n_peers; ++q) p.peer->dst[q][o] = g;
                     } else {
                         p.exch[o] = g;
                     }
@@ -702,10 +720,96 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
                 const T hi = (T)S;
                 p.exch[3 * p.n_pad] = hi;
                 p.exch[3 * p.n_pad + 1] = (T)(S - (double)hi);
+            } else if (p.mode == kReducePeer) {
+                const T hi = (T)S, lo = (T)(S - (double)hi);
+                for (int q = 0; q < p.n_peers; ++q) {
+                    p.peer->dst[q][3 * p.n_pad] = hi;
+                    p.peer->dst[q][3 * p.n_pad + 1] = lo;
+                }
             } else {
                 *p.stress_out = S;
             }
         }
+    }
+    if (p.mode == kReducePeer) {
+        // Every workgroup makes its stores visible system-wide and checks in; the
+        // last one to do so raises this rank's flag on every peer (release).
+        __shared__ int last;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope
+        __syncthreads();
+        if (tid == 0) last = atomicAdd(p.peer_counter, 1u) == gridDim.x - 1;
+        __syncthreads();
+        if (last) {
+            if (tid == 0) atomicExch(p.peer_counter, 0u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (tid < p.n_peers)
+                __hip_atomic_store(p.peer->flag[tid], p.seq, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+
+// Peer exchange, receiving side: wait until every source rank's flag has reached
+// `seq`, then X <- X + (mu V - lr * sum over ranks, in rank order).  The wait is
+// bounded: past `limit` ticks of the constant-rate clock the status word is set,
+// and every later launch returns at once without touching X ("sticky" failure,
+// reported by bb_solver_peer_status).  `arena` is this parity's first slot.
+template <typename T>
+__global__ __launch_bounds__(256) void peer_apply_kernel(
+    T *__restrict__ X, T *__restrict__ V, const T *arena, const unsigned long long *flags,
+    int world, int64_t slot_elems, int64_t n3, T lr, T mu, double *stress_out,
+    unsigned long long seq, int *status, long long limit) {
+    __shared__ int ok;
+    const int tid = threadIdx.x;
+    if (tid == 0) ok = 1;
+    __syncthreads();
+    if (tid < world) {
+        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            ok = 0;
+        } else {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(flags + 8 * tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) <
+                   seq) {
+                if (wall_clock64() - t0 > limit) {
+                    atomicExch(status, 1);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+    }
+    __syncthreads();
+    if (!ok) return;
+    // The pollers' acquire + the barrier order every thread's loads after the
+    // peers' stores; the arena is uncached memory, read past L1/L2 (sc0 sc1).
+    const int64_t e = (int64_t)blockIdx.x * 256 + tid;
+    if (e < n3) {
+        // all slots are requested before the first add (one memory round trip per
+        // eight ranks, not one per rank); the sum itself runs in rank order
+        T g = T(0);
+        for (int r0 = 0; r0 < world; r0 += 8) {
+            T v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                v[q] = r0 + q < world
+                           ? __hip_atomic_load(arena + (r0 + q) * slot_elems + e, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_SYSTEM)
+                           : T(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (r0 + q < world) g += v[q];
+        }
+        const T v = mu * V[e] - lr * g;
+        V[e] = v;
+        X[e] += v;
+    }
+    if (e == 0) {
+        double S = 0.0;
+        for (int r = 0; r < world; ++r)
+            S += (double)arena[r * slot_elems + n3] + (double)arena[r * slot_elems + n3 + 1];
+        *stress_out = S;
     }
 }
 
@@ -892,6 +996,18 @@ struct bb_solver {
     bool have_wish = false, have_coords = false, grad_pending = false;
 
     bb::Rccl::Comm comm = nullptr;  // direct RCCL path (bb_solver_comm_init), else null
+
+    // peer exchange (bb_solver_peer_*)
+    void *peer_arena = nullptr;             // this rank's receive arena (uncached)
+    int64_t peer_slot_elems = 0, peer_arena_bytes = 0;
+    std::vector<void *> peer_mapped;        // arenas of all ranks as mapped here (own = peer_arena)
+    std::vector<void *> peer_opened;        // the ones that came from hipIpcOpenMemHandle
+    void *d_peer_table = nullptr;           // PeerTable<T>[2], one per parity
+    int *d_peer_status = nullptr;           // [0] sticky time-out flag
+    unsigned *d_peer_counter = nullptr;
+    unsigned long long peer_seq = 0;        // iterations exchanged so far
+    long long peer_limit_ticks = 0;
+    bool peer_connected = false;
 
     bool timing = false;
     std::vector<hipEvent_t> ev;  // triples: start, after grad, after reduce
@@ -1108,6 +1224,16 @@ int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, doubl
     p.n_pad = s->L.n_pad;
     p.n_waves = s->n_waves;
     p.lr = (T)lr;
+    p.peer = nullptr;
+    p.peer_counter = s->d_peer_counter;
+    p.seq = 0;
+    p.n_peers = 0;
+    if (mode == kReducePeer) {
+        // the caller has bumped peer_seq: iteration k (1-based) uses parity k & 1
+        p.peer = (const PeerTable<T> *)s->d_peer_table + (s->peer_seq & 1);
+        p.seq = s->peer_seq;
+        p.n_peers = s->world;
+    }
     if (mode != kReduceStressOnly && s->n_slices > 0) {
         p.blk_ptr = s->d_s1_ptr;
         p.blk_chunk = s->d_s1_chunk;
@@ -1200,6 +1326,45 @@ int set_wish_dense_t(bb_solver *s, const double *host, int64_t ld, int kind, dou
 
 }  // namespace
 
+// ---- peer exchange ---------------------------------------------------------
+namespace {
+
+// What travels between ranks: the IPC handle of the arena plus what is needed to
+// check that both sides agree on its shape (and to short-cut ranks that live in
+// the same process, where an IPC handle cannot be opened).
+struct PeerHandle {
+    hipIpcMemHandle_t ipc;   // 64 bytes
+    uint64_t magic;
+    int64_t arena_bytes, slot_elems;
+    int64_t pid;
+    uint64_t raw;            // the exporter's own pointer (same-process ranks only)
+    int32_t rank, world, dtype, device;
+};
+static_assert(sizeof(PeerHandle) <= BB_PEER_HANDLE_BYTES, "handle blob too small");
+constexpr uint64_t kPeerMagic = 0x6262706565723031ull;  // "bbpeer01"
+
+int64_t peer_flags_offset(const bb_solver *s) {
+    return 2 * (int64_t)s->world * s->peer_slot_elems * bb::elem_size(s->dtype);
+}
+
+template <typename T>
+int build_peer_tables(bb_solver *s) {
+    PeerTable<T> tab[2];
+    memset(tab, 0, sizeof(tab));
+    const int64_t foff = peer_flags_offset(s);
+    for (int par = 0; par < 2; ++par)
+        for (int q = 0; q < s->world; ++q) {
+            char *base = (char *)s->peer_mapped[q];
+            tab[par].dst[q] = (T *)base + ((int64_t)par * s->world + s->rank) * s->peer_slot_elems;
+            tab[par].flag[q] = (unsigned long long *)(base + foff) + 8 * s->rank;
+        }
+    BB_TRY(dev_alloc((char **)&s->d_peer_table, (int64_t)sizeof(tab)));
+    BB_HIP_CHECK(hipMemcpy(s->d_peer_table, tab, sizeof(tab), hipMemcpyHostToDevice));
+    return BB_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int bb_solver_create(bb_solver **out, int64_t n_bins, int dtype, int device, int rank, int world,
@@ -1270,6 +1435,11 @@ int bb_solver_destroy(bb_solver *s) {
     hipSetDevice(s->device);
     if (s->stream || !s->own_stream) hipStreamSynchronize(s->stream);
     if (s->comm) bb::rccl().CommDestroy(s->comm);
+    for (void *m : s->peer_opened) hipIpcCloseMemHandle(m);
+    hipFree(s->peer_arena);
+    hipFree(s->d_peer_table);
+    hipFree(s->d_peer_status);
+    hipFree(s->d_peer_counter);
     for (hipEvent_t e : s->ev) hipEventDestroy(e);
     hipFree(s->d_units);
     hipFree(s->d_X);
@@ -1294,7 +1464,7 @@ int bb_solver_destroy(bb_solver *s) {
 
 int bb_solver_set_stream(bb_solver *s, void *hip_stream) {
     BB_REQUIRE(s != nullptr, "bb_solver_set_stream: solver is NULL");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     if (s->own_stream && s->stream) hipStreamDestroy(s->stream);
     s->stream = (hipStream_t)hip_stream;
@@ -1317,7 +1487,7 @@ int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld, int k
     BB_REQUIRE(kind == BB_KIND_WISH || kind == BB_KIND_COUNTS,
                "bb_solver_set_wish_dense: bad kind");
     BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_dense: alpha must be > 0");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     int rc = s->dtype == BB_F32 ? set_wish_dense_t<float>(s, host, ld, kind, alpha)
                                 : set_wish_dense_t<double>(s, host, ld, kind, alpha);
     if (rc == BB_OK) s->have_wish = true;
@@ -1334,7 +1504,7 @@ int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *
     BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_sparse: alpha must be > 0");
     BB_REQUIRE((KRnorm == nullptr) == (KRexpected == nullptr),
                "bb_solver_set_wish_sparse: KRnorm and KRexpected go together");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     const int64_t nb = s->L.n_blocks;
     std::vector<int32_t> tilemap((size_t)(nb * nb), -1);
     for (size_t t = 0; t < s->tile_I.size(); ++t)
@@ -1414,7 +1584,7 @@ int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *
 
 int bb_solver_set_wish_from_coords(bb_solver *s, const double *xstar) {
     BB_REQUIRE(s != nullptr && xstar != nullptr, "bb_solver_set_wish_from_coords: NULL argument");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     BB_HIP_CHECK(hipMemsetAsync(s->d_f64_tmp, 0, (size_t)s->L.n_pad * 3 * sizeof(double), s->stream));
     BB_HIP_CHECK(hipMemcpyAsync(s->d_f64_tmp, xstar, (size_t)s->L.n_bins * 3 * sizeof(double),
                                 hipMemcpyHostToDevice, s->stream));
@@ -1436,7 +1606,7 @@ int bb_solver_set_wish_from_coords(bb_solver *s, const double *xstar) {
 
 int bb_solver_set_coords(bb_solver *s, const double *xyz) {
     BB_REQUIRE(s != nullptr && xyz != nullptr, "bb_solver_set_coords: NULL argument");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     const int64_t n3 = s->L.n_pad * 3;
     BB_HIP_CHECK(hipMemsetAsync(s->d_f64_tmp, 0, (size_t)n3 * sizeof(double), s->stream));
     BB_HIP_CHECK(hipMemcpyAsync(s->d_f64_tmp, xyz, (size_t)s->L.n_bins * 3 * sizeof(double),
@@ -1460,7 +1630,7 @@ int bb_solver_set_coords(bb_solver *s, const double *xyz) {
 int bb_solver_get_coords(bb_solver *s, double *xyz) {
     BB_REQUIRE(s != nullptr && xyz != nullptr, "bb_solver_get_coords: NULL argument");
     if (!s->have_coords) return bb::fail(BB_ERR_STATE, "bb_solver_get_coords: no coordinates set");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     const int64_t n3 = s->L.n_pad * 3;
     const unsigned grid = (unsigned)((n3 + 255) / 256);
     if (s->dtype == BB_F32)
@@ -1492,7 +1662,7 @@ int bb_solver_iterate(bb_solver *s, int64_t iters, double lr) {
                         "bb_solver_apply");
     if (s->hist_n + iters > s->hist_cap)
         return bb::fail(BB_ERR_STATE, "bb_solver_iterate: stress history full");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     for (int64_t k = 0; k < iters; ++k) {
         hipEvent_t *ev = timing_slot(s);
         if (ev) BB_HIP_CHECK(hipEventRecord(ev[0], s->stream));
@@ -1507,7 +1677,7 @@ int bb_solver_iterate(bb_solver *s, int64_t iters, double lr) {
 
 int bb_solver_grad(bb_solver *s) {
     BB_TRY(check_ready(s, "bb_solver_grad"));
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     hipEvent_t *ev = timing_slot(s);
     if (ev) BB_HIP_CHECK(hipEventRecord(ev[0], s->stream));
     BB_TRY(launch_grad(s));
@@ -1524,7 +1694,7 @@ int bb_solver_apply(bb_solver *s, double lr) {
         return bb::fail(BB_ERR_STATE, "bb_solver_apply: no bb_solver_grad pending");
     if (s->hist_n + 1 > s->hist_cap)
         return bb::fail(BB_ERR_STATE, "bb_solver_apply: stress history full");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     const int64_t n3 = s->L.n_pad * 3;
     const unsigned grid = (unsigned)((n3 + 255) / 256);
     if (s->dtype == BB_F32)
@@ -1558,7 +1728,7 @@ int bb_solver_comm_init(bb_solver *s, const void *unique_id) {
     if (s->comm) return bb::fail(BB_ERR_STATE, "bb_solver_comm_init: communicator already made");
     const bb::Rccl &R = bb::rccl();
     if (!R.ok) return bb::fail(BB_ERR_HIP, "bb_solver_comm_init: librccl is not loadable");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     bb::Rccl::UniqueId id;
     memcpy(id.internal, unique_id, bb::kUniqueIdBytes);
     const int rc = R.CommInitRank(&s->comm, s->world, id, s->rank);
@@ -1585,7 +1755,7 @@ int bb_solver_allreduce(bb_solver *s) {
     BB_REQUIRE(s != nullptr, "bb_solver_allreduce: solver is NULL");
     if (!s->comm) return bb::fail(BB_ERR_STATE, "bb_solver_allreduce: no communicator");
     if (!s->grad_pending) return bb::fail(BB_ERR_STATE, "bb_solver_allreduce: no bb_solver_grad pending");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     return enqueue_allreduce(s);
 }
 
@@ -1595,6 +1765,168 @@ int bb_solver_iterate_dist(bb_solver *s, int64_t iters, double lr) {
         BB_TRY(bb_solver_grad(s));
         BB_TRY(bb_solver_allreduce(s));
         BB_TRY(bb_solver_apply(s, lr));
+    }
+    return BB_OK;
+}
+
+int bb_solver_peer_export(bb_solver *s, void *handle_out) {
+    BB_REQUIRE(s != nullptr && handle_out != nullptr, "bb_solver_peer_export: NULL argument");
+    BB_REQUIRE(s->world <= kMaxPeers, "bb_solver_peer_export: world > 16");
+    if (s->peer_arena) return bb::fail(BB_ERR_STATE, "bb_solver_peer_export: already exported");
+    BB_TRY(bb::enter_device(s->device));
+    const int64_t es = bb::elem_size(s->dtype);
+    s->peer_slot_elems = bb::round_up(3 * s->L.n_pad + 2, 256 / es);
+    s->peer_arena_bytes = peer_flags_offset(s) + (int64_t)s->world * 64;
+    // Uncached: written by the peers' kernels while ours is running, so nothing of
+    // it may live in this GPU's L2.  (RCCL allocates its own buffers the same way.)
+    hipError_t e = hipExtMallocWithFlags(&s->peer_arena, (size_t)s->peer_arena_bytes,
+                                         hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipExtMallocWithFlags(&s->peer_arena, (size_t)s->peer_arena_bytes,
+                                  hipDeviceMallocFinegrained);
+    }
+    if (e != hipSuccess) {
+        s->peer_arena = nullptr;
+        return bb::fail(BB_ERR_NOMEM, std::string("bb_solver_peer_export: arena: ") +
+                                          hipGetErrorString(e));
+    }
+    BB_HIP_CHECK(hipMemset(s->peer_arena, 0, (size_t)s->peer_arena_bytes));
+    BB_HIP_CHECK(hipDeviceSynchronize());
+    PeerHandle h;
+    memset(&h, 0, sizeof(h));
+    e = hipIpcGetMemHandle(&h.ipc, s->peer_arena);
+    if (e != hipSuccess) {
+        hipFree(s->peer_arena);
+        s->peer_arena = nullptr;
+        return bb::fail(BB_ERR_HIP, std::string("bb_solver_peer_export: hipIpcGetMemHandle: ") +
+                                        hipGetErrorString(e));
+    }
+    h.magic = kPeerMagic;
+    h.arena_bytes = s->peer_arena_bytes;
+    h.slot_elems = s->peer_slot_elems;
+    h.pid = (int64_t)getpid();
+    h.raw = (uint64_t)(uintptr_t)s->peer_arena;
+    h.rank = s->rank;
+    h.world = s->world;
+    h.dtype = s->dtype;
+    h.device = s->device;
+    memset(handle_out, 0, BB_PEER_HANDLE_BYTES);
+    memcpy(handle_out, &h, sizeof(h));
+    return BB_OK;
+}
+
+int bb_solver_peer_connect(bb_solver *s, const void *handles) {
+    BB_REQUIRE(s != nullptr && handles != nullptr, "bb_solver_peer_connect: NULL argument");
+    if (!s->peer_arena) return bb::fail(BB_ERR_STATE, "bb_solver_peer_connect: export first");
+    if (s->peer_connected) return bb::fail(BB_ERR_STATE, "bb_solver_peer_connect: already connected");
+    BB_TRY(bb::enter_device(s->device));
+    s->peer_mapped.assign((size_t)s->world, nullptr);
+    for (int r = 0; r < s->world; ++r) {
+        PeerHandle h;
+        memcpy(&h, (const char *)handles + (size_t)r * BB_PEER_HANDLE_BYTES, sizeof(h));
+        if (h.magic != kPeerMagic || h.rank != r || h.world != s->world || h.dtype != s->dtype ||
+            h.arena_bytes != s->peer_arena_bytes || h.slot_elems != s->peer_slot_elems)
+            return bb::fail(BB_ERR_INVALID, "bb_solver_peer_connect: handle " + std::to_string(r) +
+                                                " does not match this solver (rank order, world, "
+                                                "dtype and n_bins must agree)");
+        if (r == s->rank) {
+            s->peer_mapped[r] = s->peer_arena;
+        } else if (h.pid == (int64_t)getpid()) {
+            // same process: the exporter's pointer is valid here, but only from the
+            // same device or with peer access
+            if (h.device != s->device) {
+                hipError_t pe = hipDeviceEnablePeerAccess(h.device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                    return bb::fail(BB_ERR_HIP, std::string("bb_solver_peer_connect: peer access: ") +
+                                                    hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
+            s->peer_mapped[r] = (void *)(uintptr_t)h.raw;
+        } else {
+            void *ptr = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&ptr, h.ipc, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess)
+                return bb::fail(BB_ERR_HIP, "bb_solver_peer_connect: hipIpcOpenMemHandle(rank " +
+                                                std::to_string(r) + "): " + hipGetErrorString(e));
+            s->peer_mapped[r] = ptr;
+            s->peer_opened.push_back(ptr);
+        }
+    }
+    BB_TRY(s->dtype == BB_F32 ? build_peer_tables<float>(s) : build_peer_tables<double>(s));
+    BB_TRY(dev_alloc(&s->d_peer_status, 1));
+    BB_TRY(dev_alloc(&s->d_peer_counter, 1));
+    BB_HIP_CHECK(hipMemset(s->d_peer_status, 0, sizeof(int)));
+    BB_HIP_CHECK(hipMemset(s->d_peer_counter, 0, sizeof(unsigned)));
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->device) != hipSuccess || khz <= 0)
+        khz = 100000;  // gfx9: 100 MHz
+    (void)hipGetLastError();
+    long long ms = 10000;
+    if (const char *env = getenv("BB_PEER_TIMEOUT_MS")) {
+        const long long v = atoll(env);
+        if (v > 0) ms = v;
+    }
+    s->peer_limit_ticks = ms * khz;
+    s->peer_seq = 0;
+    s->peer_connected = true;
+    BB_HIP_CHECK(hipDeviceSynchronize());
+    return BB_OK;
+}
+
+int bb_solver_peer_status(bb_solver *s, int *status) {
+    BB_REQUIRE(s != nullptr, "bb_solver_peer_status: solver is NULL");
+    if (!s->peer_connected) return bb::fail(BB_ERR_STATE, "bb_solver_peer_status: not connected");
+    BB_TRY(bb::enter_device(s->device));
+    int st = 0;
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    BB_HIP_CHECK(hipMemcpy(&st, s->d_peer_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (status) *status = st;
+    if (st != 0)
+        return bb::fail(BB_ERR_STATE,
+                        "peer exchange: a rank did not deliver its partial within the time limit "
+                        "(BB_PEER_TIMEOUT_MS); coordinates were left at the last completed step");
+    return BB_OK;
+}
+
+int bb_solver_iterate_peer(bb_solver *s, int64_t iters, double lr) {
+    BB_TRY(check_ready(s, "bb_solver_iterate_peer"));
+    BB_REQUIRE(iters >= 0, "bb_solver_iterate_peer: iters < 0");
+    if (!s->peer_connected)
+        return bb::fail(BB_ERR_STATE, "bb_solver_iterate_peer: bb_solver_peer_connect first");
+    if (s->grad_pending)
+        return bb::fail(BB_ERR_STATE, "bb_solver_iterate_peer: a bb_solver_grad is pending");
+    if (s->hist_n + iters > s->hist_cap)
+        return bb::fail(BB_ERR_STATE, "bb_solver_iterate_peer: stress history full");
+    BB_TRY(bb::enter_device(s->device));
+    const int64_t n3 = s->L.n_pad * 3, es = bb::elem_size(s->dtype);
+    const unsigned grid = (unsigned)((n3 + 255) / 256);
+    for (int64_t k = 0; k < iters; ++k) {
+        hipEvent_t *ev = timing_slot(s);
+        if (ev) BB_HIP_CHECK(hipEventRecord(ev[0], s->stream));
+        BB_TRY(launch_grad(s));
+        if (ev) BB_HIP_CHECK(hipEventRecord(ev[1], s->stream));
+        s->peer_seq++;
+        BB_TRY(launch_reduce(s, kReducePeer, 0.0, nullptr));
+        if (ev) BB_HIP_CHECK(hipEventRecord(ev[2], s->stream));
+        const char *arena = (const char *)s->peer_arena +
+                            (int64_t)(s->peer_seq & 1) * s->world * s->peer_slot_elems * es;
+        const unsigned long long *flags =
+            (const unsigned long long *)((const char *)s->peer_arena + peer_flags_offset(s));
+        if (s->dtype == BB_F32)
+            hipLaunchKernelGGL(peer_apply_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
+                               (float *)s->d_X, (float *)s->d_V, (const float *)arena, flags,
+                               s->world, s->peer_slot_elems, n3, (float)lr, (float)s->momentum,
+                               s->d_stress_hist + s->hist_n, s->peer_seq, s->d_peer_status,
+                               s->peer_limit_ticks);
+        else
+            hipLaunchKernelGGL(peer_apply_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
+                               (double *)s->d_X, (double *)s->d_V, (const double *)arena, flags,
+                               s->world, s->peer_slot_elems, n3, lr, s->momentum,
+                               s->d_stress_hist + s->hist_n, s->peer_seq, s->d_peer_status,
+                               s->peer_limit_ticks);
+        BB_HIP_CHECK(hipGetLastError());
+        s->hist_n++;
     }
     return BB_OK;
 }
@@ -1613,7 +1945,7 @@ int bb_solver_get_exchange_buffer(bb_solver *s, void **dev_ptr) {
 
 int bb_solver_set_exchange_buffer(bb_solver *s, void *dev_ptr) {
     BB_REQUIRE(s != nullptr && dev_ptr != nullptr, "bb_solver_set_exchange_buffer: NULL argument");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     if (s->own_exch) hipFree(s->d_exch);
     s->d_exch = dev_ptr;
@@ -1624,7 +1956,7 @@ int bb_solver_set_exchange_buffer(bb_solver *s, void *dev_ptr) {
 int bb_solver_read_exchange(bb_solver *s, double *host, int64_t n) {
     BB_REQUIRE(s != nullptr && host != nullptr, "bb_solver_read_exchange: NULL argument");
     BB_REQUIRE(n == 3 * s->L.n_pad + 2, "bb_solver_read_exchange: n != exchange size");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     double *tmp = nullptr;
     BB_TRY(dev_alloc(&tmp, n));
     const unsigned grid = (unsigned)((n + 255) / 256);
@@ -1647,7 +1979,7 @@ int bb_solver_read_exchange(bb_solver *s, double *host, int64_t n) {
 int bb_solver_write_exchange(bb_solver *s, const double *host, int64_t n) {
     BB_REQUIRE(s != nullptr && host != nullptr, "bb_solver_write_exchange: NULL argument");
     BB_REQUIRE(n == 3 * s->L.n_pad + 2, "bb_solver_write_exchange: n != exchange size");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     double *tmp = nullptr;
     BB_TRY(dev_alloc(&tmp, n));
     hipError_t e = hipMemcpyAsync(tmp, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice,
@@ -1674,7 +2006,7 @@ int bb_solver_matvec_sq(bb_solver *s, const double *x, double *y) {
     if (!s->have_wish) return bb::fail(BB_ERR_STATE, "bb_solver_matvec_sq: no wish distances set");
     if (s->grad_pending)
         return bb::fail(BB_ERR_STATE, "bb_solver_matvec_sq: a bb_solver_grad is pending");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     const int64_t n3 = s->L.n_pad * 3, es = bb::elem_size(s->dtype);
     void *d_in = nullptr;
     BB_TRY(dev_alloc((char **)&d_in, n3 * es));
@@ -1719,7 +2051,7 @@ int bb_solver_matvec_sq(bb_solver *s, const double *x, double *y) {
 int bb_solver_stress(bb_solver *s, double *stress) {
     BB_TRY(check_ready(s, "bb_solver_stress"));
     BB_REQUIRE(stress != nullptr, "bb_solver_stress: stress is NULL");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     BB_TRY(launch_grad(s));
     BB_TRY(launch_reduce(s, kReduceStressOnly, 0.0, s->d_stress_scalar));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
@@ -1729,7 +2061,7 @@ int bb_solver_stress(bb_solver *s, double *stress) {
 
 int bb_solver_get_stress_history(bb_solver *s, double *out, int64_t cap, int64_t *n) {
     BB_REQUIRE(s != nullptr && n != nullptr, "bb_solver_get_stress_history: NULL argument");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     *n = s->hist_n;
     const int64_t m = std::min(cap, s->hist_n);
@@ -1741,14 +2073,14 @@ int bb_solver_get_stress_history(bb_solver *s, double *out, int64_t cap, int64_t
 
 int bb_solver_sync(bb_solver *s) {
     BB_REQUIRE(s != nullptr, "bb_solver_sync: solver is NULL");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     return BB_OK;
 }
 
 int bb_solver_set_timing(bb_solver *s, int enabled) {
     BB_REQUIRE(s != nullptr, "bb_solver_set_timing: solver is NULL");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     if (enabled && s->ev.empty()) {
         s->ev.resize(3 * kMaxTimedLaunches);
@@ -1762,7 +2094,7 @@ int bb_solver_set_timing(bb_solver *s, int enabled) {
 int bb_solver_get_timing(bb_solver *s, double *grad_ms_avg, double *reduce_ms_avg,
                          int64_t *launches) {
     BB_REQUIRE(s != nullptr, "bb_solver_get_timing: solver is NULL");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     double g = 0.0, r = 0.0;
     const size_t n = s->ev_used / 3;
@@ -1779,12 +2111,27 @@ int bb_solver_get_timing(bb_solver *s, double *grad_ms_avg, double *reduce_ms_av
     return BB_OK;
 }
 
+int bb_solver_get_step_timing(bb_solver *s, double *step_ms_avg) {
+    BB_REQUIRE(s != nullptr && step_ms_avg != nullptr, "bb_solver_get_step_timing: NULL argument");
+    BB_TRY(bb::enter_device(s->device));
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    const size_t n = s->ev_used / 3;
+    double t = 0.0;
+    for (size_t k = 0; k + 1 < n; ++k) {
+        float a = 0.f;
+        BB_HIP_CHECK(hipEventElapsedTime(&a, s->ev[3 * k], s->ev[3 * k + 3]));
+        t += a;
+    }
+    *step_ms_avg = n > 1 ? t / (double)(n - 1) : 0.0;
+    return BB_OK;
+}
+
 int bb_solver_measure_stream_read(bb_solver *s, int launches, double *ms_avg) {
     BB_REQUIRE(s != nullptr && ms_avg != nullptr, "bb_solver_measure_stream_read: NULL argument");
     BB_REQUIRE(launches >= 1 && launches <= 1000, "bb_solver_measure_stream_read: bad launches");
     if (!s->have_wish)
         return bb::fail(BB_ERR_STATE, "bb_solver_measure_stream_read: no wish distances set");
-    BB_HIP_CHECK(hipSetDevice(s->device));
+    BB_TRY(bb::enter_device(s->device));
     hipEvent_t e0, e1;
     BB_HIP_CHECK(hipEventCreate(&e0));
     BB_HIP_CHECK(hipEventCreate(&e1));

@@ -42,7 +42,10 @@ class HipEngine(object):
             None if ti is None else ti.ctypes.data_as(_lib.p_i32),
             None if tj is None else tj.ctypes.data_as(_lib.p_i32), nt), "bb_solver_create")
         self._exch = None
-        self._comm_state = None     # "rccl" | "torch" once the multi-rank path is chosen
+        self._comm_state = None     # "peer" | "rccl" | "torch" | "host" once chosen
+        self._peer = None           # outcome of peer_setup()
+        self._peer_error = ""
+        self._comm_trial = None     # timings of select_exchange's trial, if one ran
 
     # -- lifetime ---------------------------------------------------------
     def close(self):
@@ -193,6 +196,42 @@ class HipEngine(object):
         _lib.check(self._lib.bb_solver_iterate_dist(self._h, int(iters), float(lr)),
                    "bb_solver_iterate_dist")
 
+    def peer_setup(self):
+        """Connect the peer exchange (one-shot all-reduce inside the solver's own
+        kernels, include/blueberry_hip.h): every rank exports its receive arena,
+        torch.distributed only carries the 128-byte handles, every rank maps all
+        arenas.  Collective.  Returns False -- on every rank alike -- when any
+        rank could not export or map, so that the caller can fall back to RCCL."""
+        import ctypes
+        import torch.distributed as dist
+        if self._peer is not None:
+            return self._peer
+        buf = ctypes.create_string_buffer(_lib.BB_PEER_HANDLE_BYTES)
+        mine = buf.raw if self._lib.bb_solver_peer_export(self._h, buf) == _lib.BB_OK else None
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine)
+        ok = all(h is not None for h in handles)
+        if ok:
+            ok = self._lib.bb_solver_peer_connect(self._h, b"".join(handles)) == _lib.BB_OK
+        if not ok:
+            self._peer_error = _lib.last_error()
+        oks = [None] * self.world
+        dist.all_gather_object(oks, bool(ok))
+        self._peer = all(oks)
+        return self._peer
+
+    def iterate_peer(self, iters, lr):
+        """`iters` x { grad, reduce + push to every peer, wait + rank-ordered sum +
+        update }, all enqueued by one C call."""
+        _lib.check(self._lib.bb_solver_iterate_peer(self._h, int(iters), float(lr)),
+                   "bb_solver_iterate_peer")
+
+    def peer_status(self):
+        """Synchronise and raise if a peer wait ran into its time limit."""
+        st = _lib.c_int()
+        _lib.check(self._lib.bb_solver_peer_status(self._h, st), "bb_solver_peer_status")
+        return int(st.value)
+
     def exchange_tensor(self):
         """A torch tensor aliasing the exchange buffer [g (n_pad,3) | hi | lo].
 
@@ -228,7 +267,10 @@ class HipEngine(object):
     def timing(self):
         g, r, n = _lib.c_dbl(), _lib.c_dbl(), _lib.c_i64()
         _lib.check(self._lib.bb_solver_get_timing(self._h, g, r, n), "bb_solver_get_timing")
-        return {"grad_ms": float(g.value), "reduce_ms": float(r.value), "launches": int(n.value)}
+        st = _lib.c_dbl()
+        _lib.check(self._lib.bb_solver_get_step_timing(self._h, st), "bb_solver_get_step_timing")
+        return {"grad_ms": float(g.value), "reduce_ms": float(r.value), "launches": int(n.value),
+                "step_ms": float(st.value)}
 
     def stream_read_ms(self, launches=10):
         """Average ms of a read-only sweep over the resident units (measurement aid)."""
@@ -447,6 +489,8 @@ class StructureSolver(object):
             eng.set_coords(init)
             if self.momentum:
                 eng.set_momentum(self.momentum)
+            if world > 1:
+                select_exchange(eng, lr)
             if self.tol is None:
                 run_iterations(eng, self.n_iter, lr, world)
             else:
@@ -529,25 +573,102 @@ def spectral_init(eng, n, world, n_iter=40, seed=0):
     return (V @ evecs[:, order]) * numpy.sqrt(numpy.maximum(evals[order], 0.0))
 
 
+def select_exchange(eng, lr, trial=True):
+    """Decide, once per engine and identically on every rank, how the partial
+    gradients are summed over the ranks.  Collective.
+
+    BB_COMM = auto (default) | peer | rccl | torch | host
+      peer   one-shot exchange inside the solver's own kernels (IPC-mapped arenas)
+      rccl   the library's own RCCL communicator, all-reduce enqueued from C
+      torch  torch.distributed all-reduce on a tensor aliasing the exchange buffer
+      host   exchange buffer staged through host memory (gloo / CPU rehearsals)
+    auto on an RCCL job sets up peer and rccl, and -- when `trial` is true and the
+    coordinates have just been set -- runs a few iterations through both from the
+    same start: peer is taken only if its coordinates agree with RCCL's and it is
+    faster on the slowest rank; the start is restored afterwards.  Without a trial
+    auto means rccl.  The outcome is kept in eng._comm_state / eng._comm_trial."""
+    if getattr(eng, "_comm_state", None):
+        return eng._comm_state
+    import time
+    import torch.distributed as dist
+    want = os.environ.get("BB_COMM", "auto")
+    if want not in ("auto", "peer", "rccl", "torch", "host"):
+        raise ValueError("BB_COMM must be auto, peer, rccl, torch or host, not %r" % want)
+    native = hasattr(eng, "peer_setup")
+    nccl = dist.get_backend() == "nccl"
+    state = None
+    if not native or want == "host" or (not nccl and want != "peer"):
+        state = "host"
+    elif want == "peer":
+        if not eng.peer_setup():
+            raise RuntimeError("BB_COMM=peer but the peer exchange could not be set up: %s"
+                               % eng._peer_error)
+        state = "peer"
+    elif want == "torch":
+        state = "torch"
+    elif want == "rccl":
+        state = "rccl" if eng.comm_setup() else "torch"
+    else:
+        have_rccl = eng.comm_setup()
+        have_peer = bool(trial) and eng.peer_setup()
+        if have_rccl and have_peer:
+            x0 = eng.get_coords()
+            runs = {}
+            for name, step in (("rccl", eng.iterate_dist), ("peer", eng.iterate_peer)):
+                eng.set_coords(x0)
+                ok = True
+                try:
+                    step(1, lr)
+                    x1 = eng.get_coords()
+                    step(3, lr)
+                    eng.sync()
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    step(10, lr)
+                    eng.sync()
+                    dt = (time.perf_counter() - t0) / 10
+                    if name == "peer":
+                        eng.peer_status()
+                except RuntimeError:
+                    ok, x1, dt = False, None, float("inf")
+                runs[name] = (ok, x1, dt)
+            eng.set_coords(x0)
+            agree = bool(runs["rccl"][0] and runs["peer"][0] and numpy.allclose(
+                runs["rccl"][1], runs["peer"][1], rtol=1e-4,
+                atol=1e-6 * float(numpy.abs(x0).max() + 1e-30)))
+            mine = (agree, runs["rccl"][2], runs["peer"][2])
+            every = [None] * eng.world
+            dist.all_gather_object(every, mine)
+            t_rccl = max(e[1] for e in every)
+            t_peer = max(e[2] for e in every)
+            use_peer = all(e[0] for e in every) and t_peer < t_rccl
+            eng._comm_trial = {"agree": all(e[0] for e in every), "rccl_ms": t_rccl * 1e3,
+                               "peer_ms": t_peer * 1e3}
+            state = "peer" if use_peer else "rccl"
+        elif have_rccl:
+            state = "rccl"
+        else:
+            state = "torch"
+    eng._comm_state = state
+    return state
+
+
 def run_iterations(eng, n_iter, lr, world):
     """n_iter solver iterations on an engine whose inputs are set.
 
     world == 1: the whole loop is enqueued by one C call.  world > 1: per
-    iteration, local partial gradient -> all-reduce(sum) -> identical update on
-    every rank, so the replicas of X stay bit-identical."""
+    iteration, local partial gradient -> sum over ranks -> identical update on
+    every rank, so the replicas of X stay identical; `select_exchange` picks the
+    transport."""
     if world == 1:
         eng.iterate(n_iter, lr)
         return
-    import torch.distributed as dist
-    if dist.get_backend() == "nccl":
-        if not getattr(eng, "_comm_state", None):
-            # first choice: the library's own RCCL communicator (no framework in the
-            # loop); BB_COMM=torch forces the torch.distributed all-reduce instead
-            direct = os.environ.get("BB_COMM", "rccl") != "torch" and hasattr(eng, "comm_setup")
-            eng._comm_state = "rccl" if (direct and eng.comm_setup()) else "torch"
-        if eng._comm_state == "rccl":
-            eng.iterate_dist(n_iter, lr)
-            return
+    state = select_exchange(eng, lr, trial=False)
+    if state == "peer":
+        eng.iterate_peer(n_iter, lr)
+    elif state == "rccl":
+        eng.iterate_dist(n_iter, lr)
+    elif state == "torch":
         t = eng.exchange_tensor()
         for _ in range(n_iter):
             eng.grad()

@@ -184,6 +184,29 @@ BB_API int bb_solver_comm_init(bb_solver *s, const void *unique_id_128_bytes);
 BB_API int bb_solver_allreduce(bb_solver *s);
 BB_API int bb_solver_iterate_dist(bb_solver *s, int64_t iters, double lr);
 
+/* Peer exchange: a one-shot all-reduce over xGMI written into the solver's own
+ * kernels -- no collective library in the loop.  Every rank owns a receive
+ * arena (uncached device memory, 2 parities x world slots of the exchange
+ * vector + one sequence flag per source rank) that the other ranks map through
+ * HIP IPC.  The last reduce launch of an iteration stores this rank's partial
+ * gradient straight into its slot on every peer and then raises its flag there;
+ * the update kernel waits (bounded) for all `world` flags, sums the slots in
+ * RANK ORDER -- bit-identical coordinates on every rank -- and applies the step.
+ *   bb_solver_peer_export   allocate the arena, write its handle (BB_PEER_HANDLE_BYTES)
+ *   bb_solver_peer_connect  map the arenas of all ranks (handles in rank order;
+ *                           collective: every rank must have exported)
+ *   bb_solver_iterate_peer  `iters` x { grad, reduce+push, wait+sum+apply }
+ *   bb_solver_peer_status   0 = healthy; 1 = a wait ran into the time limit
+ *                           (BB_PEER_TIMEOUT_MS, default 10000): later launches
+ *                           skip their update and this call reports BB_ERR_STATE
+ * The handles travel by whatever the caller has (MPI_Allgather, torch.distributed,
+ * a file).  All ranks must be on one node with peer access between their GPUs. */
+#define BB_PEER_HANDLE_BYTES 128
+BB_API int bb_solver_peer_export(bb_solver *s, void *handle_out);
+BB_API int bb_solver_peer_connect(bb_solver *s, const void *handles_rank_order);
+BB_API int bb_solver_iterate_peer(bb_solver *s, int64_t iters, double lr);
+BB_API int bb_solver_peer_status(bb_solver *s, int *status);
+
 /* Host-staged access to the exchange buffer, widened to float64, for callers
  * whose collective runs on host memory (MPI, gloo): read after bb_solver_grad,
  * sum over ranks, write back, then bb_solver_apply.  n = bb_solver_exchange_size. */
@@ -212,6 +235,10 @@ BB_API int bb_solver_sync(bb_solver *s);
 BB_API int bb_solver_set_timing(bb_solver *s, int enabled);
 BB_API int bb_solver_get_timing(bb_solver *s, double *grad_ms_avg, double *reduce_ms_avg,
                                 int64_t *launches);
+/* The same events, start of one timed iteration to start of the next: the whole
+ * device-side step including the exchange, the update and the gaps between
+ * launches (average over consecutive timed iterations; 0 with fewer than two). */
+BB_API int bb_solver_get_step_timing(bb_solver *s, double *step_ms_avg);
 /* Measurement aid: average duration of a kernel that only READS this rank's
  * resident units (same grid, same per-wave chunks, same 8-row window, no
  * arithmetic) -- the practical HBM ceiling for the access pattern, to put

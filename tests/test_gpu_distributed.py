@@ -30,18 +30,21 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n, k, dtype, q):
+def _worker(rank, world, port, n, k, dtype, q, comm="host"):
     try:
         sys.path.insert(0, ROOT)
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
+        os.environ["BB_COMM"] = comm
+        os.environ["BB_PEER_TIMEOUT_MS"] = "5000"
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import blueberry_amd as bb
         from tests import _oracle
         xs = _oracle.random_walk(n)
         w = _oracle.wish_from_coords(xs)
-        s = bb.StructureSolver(n_iter=k, dtype=dtype, kind="wish", device=0)
+        s = bb.StructureSolver(n_iter=k, dtype=dtype, kind="wish", device=0,
+                               momentum=0.3 if comm == "peer" else 0.0)
         s.fit(w, init=_oracle.noisy_init(xs))
         band = bb.count_band_regions(_oracle.golden("band_count")["in_gappy_n5000"],
                                      distributed=True)
@@ -52,16 +55,20 @@ def _worker(rank, world, port, n, k, dtype, q):
         q.put((rank, traceback.format_exc(), None, None))
 
 
-@pytest.mark.parametrize("dtype,tol", [("float64", 1e-12), ("float32", 1e-5)])
-def test_two_ranks_share_one_gpu(dtype, tol):
+@pytest.mark.parametrize("dtype,tol,world,comm", [
+    ("float64", 1e-12, 2, "host"), ("float32", 1e-5, 2, "host"),
+    # the peer exchange between real processes: arenas mapped through HIP IPC,
+    # flags and partials written by the other process's kernels
+    ("float64", 1e-12, 2, "peer"), ("float32", 1e-5, 2, "peer"), ("float32", 1e-5, 4, "peer")])
+def test_ranks_share_one_gpu(dtype, tol, world, comm):
     import torch.multiprocessing as mp
     import blueberry_amd as bb
     from tests import _oracle
-    n, k, world = 1300, 5, 2
+    n, k = 1300, 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, k, dtype, q))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, k, dtype, q, comm))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -72,14 +79,89 @@ def test_two_ranks_share_one_gpu(dtype, tol):
         assert not isinstance(r[1], str), r[1]
     xs = _oracle.random_walk(n)
     w = _oracle.wish_from_coords(xs)
-    one = bb.StructureSolver(n_iter=k, dtype=dtype, kind="wish", distributed=False)
+    one = bb.StructureSolver(n_iter=k, dtype=dtype, kind="wish", distributed=False,
+                             momentum=0.3 if comm == "peer" else 0.0)
     one.fit(w, init=_oracle.noisy_init(xs))
     for rank, X, hist, band in results:
         assert numpy.abs(X - one.structure_).max() < tol * numpy.abs(one.structure_).max()
         assert numpy.abs(hist / one.stress_ - 1).max() < tol
         assert band == int(_oracle.golden("band_count")["out_gappy_n5000"])
-    assert numpy.array_equal(results[0][1], results[1][1])
-    assert numpy.array_equal(results[0][2], results[1][2])
+    for r in results[1:]:
+        assert numpy.array_equal(results[0][1], r[1])
+        assert numpy.array_equal(results[0][2], r[2])
+
+
+def _peer_engines(world, n, dtype, wish, x0, mu=0.0):
+    """`world` ranks inside this process, one HipEngine (own stream) each, their
+    receive arenas connected directly (same-process shortcut of peer_connect)."""
+    import ctypes
+    from blueberry_amd import _lib
+    from blueberry_amd.solver import HipEngine
+    lib = _lib.load()
+    engs = [HipEngine(n, dtype, rank=r, world=world) for r in range(world)]
+    blobs = []
+    for e in engs:
+        buf = ctypes.create_string_buffer(_lib.BB_PEER_HANDLE_BYTES)
+        _lib.check(lib.bb_solver_peer_export(e._h, buf), "export")
+        blobs.append(buf.raw)
+    for e in engs:
+        _lib.check(lib.bb_solver_peer_connect(e._h, b"".join(blobs)), "connect")
+        e.set_wish_dense(wish, "wish", 3.0)
+        e.set_coords(x0)
+        e.set_momentum(mu)
+    return engs
+
+
+@pytest.mark.parametrize("dtype,tol,world", [("float32", 1e-5, 2), ("float64", 1e-12, 2),
+                                             ("float32", 1e-5, 3)])
+def test_peer_exchange_in_one_process(dtype, tol, world, monkeypatch):
+    """Ranks on separate streams of one process: every iteration of every rank is
+    enqueued up front, the kernels meet through the arenas' flags."""
+    monkeypatch.setenv("BB_PEER_TIMEOUT_MS", "5000")
+    from blueberry_amd.solver import HipEngine
+    from tests import _oracle
+    n, k = 1100, 7
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    x0 = _oracle.noisy_init(xs)
+    lr = 1.0 / (2 * n)
+    engs = _peer_engines(world, n, dtype, w, x0, mu=0.2)
+    for it in (3, k - 3):                       # two calls: the sequence carries over
+        for e in engs:
+            e.iterate_peer(it, lr)
+    got = []
+    for e in engs:
+        assert e.peer_status() == 0
+        got.append((e.get_coords(), e.stress_history()))
+        e.close()
+    one = HipEngine(n, dtype)
+    one.set_wish_dense(w, "wish", 3.0)
+    one.set_coords(x0)
+    one.set_momentum(0.2)
+    one.iterate(k, lr)
+    X1, h1 = one.get_coords(), one.stress_history()
+    one.close()
+    for X, h in got:
+        assert numpy.array_equal(X, got[0][0]) and numpy.array_equal(h, got[0][1])
+        assert numpy.abs(X - X1).max() < tol * numpy.abs(X1).max()
+        assert h.shape == h1.shape and numpy.abs(h / h1 - 1).max() < tol
+
+
+def test_peer_exchange_times_out_cleanly(monkeypatch):
+    """A rank whose peer never delivers must not hang: the wait is bounded, the
+    update is skipped, the failure is sticky and reported."""
+    monkeypatch.setenv("BB_PEER_TIMEOUT_MS", "200")
+    from tests import _oracle
+    n = 600
+    xs = _oracle.random_walk(n)
+    x0 = _oracle.noisy_init(xs)
+    engs = _peer_engines(2, n, "float32", _oracle.wish_from_coords(xs), x0)
+    engs[0].iterate_peer(3, 1.0 / (2 * n))      # rank 1 never runs
+    with pytest.raises(RuntimeError, match="time limit"):
+        engs[0].peer_status()
+    assert numpy.array_equal(engs[0].get_coords(), x0.astype(numpy.float32).astype(numpy.float64))
+    for e in engs:
+        e.close()
 
 
 _NCCL_SCRIPT = r"""
@@ -92,21 +174,34 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 import blueberry_amd as bb
 from blueberry_amd import _lib
-from blueberry_amd.solver import HipEngine, run_iterations
+from blueberry_amd.solver import HipEngine, run_iterations, select_exchange
 from tests import _oracle
 n, k = 900, 6
 xs = _oracle.random_walk(n); w = _oracle.wish_from_coords(xs); x0 = _oracle.noisy_init(xs)
 lr = 1.0 / (2 * n)
 out = {}
 # world=2 forces grad/all-reduce/apply; BB_COMM picks the collective's owner
-for name, world, comm in (("fused", 1, None), ("exchange", 2, "rccl"), ("torch", 2, "torch")):
+for name, world, comm in (("fused", 1, None), ("exchange", 2, "rccl"), ("torch", 2, "torch"),
+                          ("peer", 2, "peer"), ("auto", 2, "auto")):
     if comm: os.environ["BB_COMM"] = comm
     e = HipEngine(n, "float32")
     e.set_wish_dense(w, "wish", 3.0); e.set_coords(x0)
-    run_iterations(e, k, lr, world)
-    assert e._comm_state == comm, (e._comm_state, comm)
+    if comm == "auto":
+        # the trial: both transports from the same start, coordinates compared, the
+        # faster one kept, the start restored
+        state = select_exchange(e, lr)
+        assert state in ("peer", "rccl") and e._comm_trial["agree"], (state, e._comm_trial)
+        assert numpy.array_equal(e.get_coords(), x0.astype(numpy.float32).astype(numpy.float64))
+        assert e.stress_history().size == 0
+        run_iterations(e, k, lr, world)
+    else:
+        run_iterations(e, k, lr, world)
+        assert e._comm_state == comm, (e._comm_state, comm)
     out[name] = (e.get_coords(), e.stress_history()); e.close()
 assert numpy.array_equal(out["torch"][0], out["exchange"][0])      # same kernels, same sums
+assert numpy.array_equal(out["peer"][0], out["exchange"][0])       # one rank: nothing to reorder
+assert numpy.array_equal(out["auto"][0], out["exchange"][0])
+assert numpy.array_equal(out["peer"][1], out["exchange"][1])
 assert len(_lib.hip_runtimes_loaded()) == 1, _lib.hip_runtimes_loaded()
 assert numpy.abs(out["fused"][0] - out["exchange"][0]).max() < 1e-5 * numpy.abs(out["fused"][0]).max()
 assert numpy.abs(out["fused"][1] / out["exchange"][1] - 1).max() < 1e-5
