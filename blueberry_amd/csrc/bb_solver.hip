@@ -1010,6 +1010,8 @@ struct bb_solver {
     bool peer_connected = false;
 
     bool timing = false;
+    int timing_stride = 1;      // events on every timing_stride-th iteration
+    int64_t timing_iter = 0;    // iterations seen since timing was (re-)enabled
     std::vector<hipEvent_t> ev;  // triples: start, after grad, after reduce
     size_t ev_used = 0;
 };
@@ -1261,7 +1263,8 @@ int launch_reduce(bb_solver *s, int mode, double lr, double *stress_out, double 
 }
 
 hipEvent_t *timing_slot(bb_solver *s) {
-    if (!s->timing || s->ev_used + 3 > s->ev.size()) return nullptr;
+    if (!s->timing) return nullptr;
+    if (s->timing_iter++ % s->timing_stride != 0 || s->ev_used + 3 > s->ev.size()) return nullptr;
     hipEvent_t *e = &s->ev[s->ev_used];
     s->ev_used += 3;
     return e;
@@ -2087,6 +2090,8 @@ int bb_solver_set_timing(bb_solver *s, int enabled) {
         for (auto &e : s->ev) BB_HIP_CHECK(hipEventCreate(&e));
     }
     s->timing = enabled != 0;
+    s->timing_stride = enabled > 1 ? enabled : 1;
+    s->timing_iter = 0;
     s->ev_used = 0;
     return BB_OK;
 }
@@ -2122,7 +2127,7 @@ int bb_solver_get_step_timing(bb_solver *s, double *step_ms_avg) {
         BB_HIP_CHECK(hipEventElapsedTime(&a, s->ev[3 * k], s->ev[3 * k + 3]));
         t += a;
     }
-    *step_ms_avg = n > 1 ? t / (double)(n - 1) : 0.0;
+    *step_ms_avg = n > 1 ? t / (double)(n - 1) / s->timing_stride : 0.0;
     return BB_OK;
 }
 

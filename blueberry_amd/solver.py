@@ -261,7 +261,8 @@ class HipEngine(object):
 
     # -- measurement ------------------------------------------------------
     def set_timing(self, enabled):
-        _lib.check(self._lib.bb_solver_set_timing(self._h, 1 if enabled else 0),
+        """True / 1: HIP events around every iteration; k > 1: every k-th; False: off."""
+        _lib.check(self._lib.bb_solver_set_timing(self._h, int(enabled)),
                    "bb_solver_set_timing")
 
     def timing(self):

@@ -230,8 +230,11 @@ BB_API int bb_solver_get_stress_history(bb_solver *s, double *out, int64_t cap, 
 BB_API int bb_solver_sync(bb_solver *s);
 
 /* HIP-event timing of the dominant kernel (stress+gradient) and of the
- * reduce/update kernel on the solver's stream.  Averages are over the
- * launches since timing was (re-)enabled. */
+ * reduce/update kernel on the solver's stream.  Averages are over the timed
+ * launches since timing was (re-)enabled.  enabled = 1: every iteration is
+ * timed; enabled = k > 1: every k-th one (three event records cost about 10 us
+ * of stream time per timed iteration on MI355X, which matters once a step is
+ * ~0.1 ms); 0: off. */
 BB_API int bb_solver_set_timing(bb_solver *s, int enabled);
 BB_API int bb_solver_get_timing(bb_solver *s, double *grad_ms_avg, double *reduce_ms_avg,
                                 int64_t *launches);

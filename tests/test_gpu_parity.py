@@ -676,3 +676,27 @@ def test_contactmap_file_constructor_matches_reference(tmp_path):
     assert numpy.array_equal(cm.regions, z["cm2_regions"])
     cm.normalize()
     assert numpy.array_equal(cm.matrix, z["cm2_matrix_norm"])
+
+
+def test_event_timing_every_kth_iteration():
+    """bb_solver_set_timing(k): events on every k-th iteration only; the averages
+    are per timed launch and the step time is start-to-start / k."""
+    from blueberry_amd.solver import HipEngine
+    from tests import _oracle
+    n = 2000
+    xs = _oracle.random_walk(n)
+    e = HipEngine(n, "float32")
+    e.set_wish_from_coords(xs)
+    e.set_coords(_oracle.noisy_init(xs))
+    e.set_timing(4)
+    e.iterate(16, 1.0 / (2 * n))
+    t4 = e.timing()
+    assert t4["launches"] == 4 and t4["grad_ms"] > 0 and t4["reduce_ms"] > 0
+    assert 0 < t4["step_ms"] < 10.0        # start-to-start of timed iterations / 4
+    e.set_timing(True)
+    e.iterate(5, 1.0 / (2 * n))
+    assert e.timing()["launches"] == 5
+    e.set_timing(False)
+    e.iterate(3, 1.0 / (2 * n))
+    assert e.timing()["launches"] == 0      # switching resets; nothing recorded while off
+    e.close()
