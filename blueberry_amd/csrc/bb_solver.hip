@@ -655,6 +655,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
     constexpr int NE = (CH + 255) / 256;
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) T push_stage[CH];   // peer mode only
     if (p.mode != kReduceStressOnly) {
         const int64_t k0 = p.blk_ptr[b], k1 = p.blk_ptr[b + 1];
         T acc[NE];
@@ -695,11 +696,24 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
                         p.V[o] = v;
                         p.X[o] += v;
                     } else if (p.mode == kReducePeer) {
-                        for (int q = 0; q < p.n_peers; ++q) p.peer->dst[q][o] = g;
+                        push_stage[e] = g;
                     } else {
                         p.exch[o] = g;
                     }
                 }
+            }
+        }
+        if (p.mode == kReducePeer) {
+            // the block's 3*vw values go out as 16-byte stores, 1 KiB per wave
+            // instruction and peer: what crosses xGMI is long contiguous bursts
+            typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+            constexpr int NV = CH * (int)sizeof(T) / 16;
+            __syncthreads();
+            const vec_t *src = (const vec_t *)push_stage;
+            for (int v = tid; v < NV; v += 256) {
+                const vec_t val = src[v];
+                for (int q = 0; q < p.n_peers; ++q)
+                    ((vec_t *)(p.peer->dst[q] + (int64_t)b * CH))[v] = val;
             }
         }
     }
