@@ -630,8 +630,9 @@ def select_exchange(eng, lr, trial=True):
                     dt = (time.perf_counter() - t0) / 10
                     if name == "peer":
                         eng.peer_status()
-                except RuntimeError:
+                except Exception as exc:       # a transport that fails here is just not used
                     ok, x1, dt = False, None, float("inf")
+                    eng._comm_trial_error = "%s: %s" % (name, exc)
                 runs[name] = (ok, x1, dt)
             eng.set_coords(x0)
             agree = bool(runs["rccl"][0] and runs["peer"][0] and numpy.allclose(
@@ -643,8 +644,10 @@ def select_exchange(eng, lr, trial=True):
             t_rccl = max(e[1] for e in every)
             t_peer = max(e[2] for e in every)
             use_peer = all(e[0] for e in every) and t_peer < t_rccl
-            eng._comm_trial = {"agree": all(e[0] for e in every), "rccl_ms": t_rccl * 1e3,
-                               "peer_ms": t_peer * 1e3}
+            ms = lambda t: t * 1e3 if numpy.isfinite(t) else None
+            eng._comm_trial = {"agree": all(e[0] for e in every), "rccl_ms": ms(t_rccl),
+                               "peer_ms": ms(t_peer),
+                               "error": getattr(eng, "_comm_trial_error", None)}
             state = "peer" if use_peer else "rccl"
         elif have_rccl:
             state = "rccl"
