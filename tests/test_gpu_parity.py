@@ -244,6 +244,40 @@ def test_rank_shares_sum_to_full_gradient(oracle, world):
         assert numpy.abs(g_sum - g_ref).max() < tol * numpy.abs(g_ref).max()
 
 
+def test_genome_50kb_sized_eight_shares_sum_to_full_gradient():
+    """BASELINE config 4 at its real size (N = 61,914, sharded 8 ways): the eight
+    shares' partial gradients and stresses, summed as the exchange sums them, equal
+    the single-rank sweep of the whole matrix; the shares are balanced to one unit.
+    No oracle at this size: GPU against GPU, plus exact bookkeeping."""
+    n, world = 61914, 8
+    xs = _oracle.random_walk(n)
+    x0 = _oracle.noisy_init(xs)
+    one = HipEngine(n, "float32")
+    one.set_wish_from_coords(xs)
+    one.set_coords(x0)
+    one.grad()
+    full = one.read_exchange()
+    n_units = one.layout()["n_units"]
+    one.close()
+    total = numpy.zeros_like(full)
+    sizes = []
+    for rank in range(world):
+        e = HipEngine(n, "float32", rank=rank, world=world)
+        lay = e.layout()
+        sizes.append(lay["u_end"] - lay["u_begin"])
+        e.set_wish_from_coords(xs)
+        e.set_coords(x0)
+        e.grad()
+        total += e.read_exchange()
+        e.close()
+    assert sum(sizes) == n_units and max(sizes) - min(sizes) <= 1
+    s_full, s_sum = full[-2] + full[-1], total[-2] + total[-1]
+    assert abs(s_sum / s_full - 1) < 1e-6
+    g_full, g_sum = full[:3 * n], total[:3 * n]
+    assert numpy.abs(g_sum - g_full).max() < 1e-5 * numpy.abs(g_full).max()
+    assert not total[3 * n:-2].any()
+
+
 def test_device_generated_wish_equals_host_matrix():
     n = 777
     xs, w, x0 = _problem(n)
