@@ -149,6 +149,34 @@ def load():
     return _cached
 
 
+_cached_mt = None
+
+
+def solve_mt(wish, X0, iters, lr, threads, f64=True):
+    """bbo_solve on `threads` host cores (oracle/bb_oracle_mt.c, OpenMP): the
+    multi-core cpu_baseline of bench.py.  Raises OSError if it cannot be built or
+    loaded (no libgomp): callers fall back to the scalar oracle."""
+    global _cached_mt
+    if _cached_mt is None:
+        so = os.path.join(ORACLE_DIR, "libbb_oracle_mt.so")
+        src = os.path.join(ORACLE_DIR, "bb_oracle_mt.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libbb_oracle_mt.so"])
+        lib = ctypes.CDLL(so)
+        lib.bbo_solve_mt.restype = ctypes.c_int
+        lib.bbo_solve_mt.argtypes = [p_dbl, c_long, c_long, p_dbl, c_long, c_dbl, ctypes.c_int,
+                                     p_dbl, ctypes.c_int]
+        _cached_mt = lib
+    w = numpy.ascontiguousarray(wish, dtype=numpy.float64)
+    X = numpy.ascontiguousarray(X0, dtype=numpy.float64).copy()
+    hist = numpy.zeros(iters)
+    rc = _cached_mt.bbo_solve_mt(_p(w), w.shape[0], w.shape[1], _p(X), int(iters), float(lr),
+                                 1 if f64 else 0, _p(hist), int(threads))
+    if rc != 0:
+        raise MemoryError("bbo_solve_mt: out of memory")
+    return X, hist
+
+
 def golden(name):
     return numpy.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
 

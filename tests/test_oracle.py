@@ -172,3 +172,20 @@ def test_momentum_zero_is_plain_solve(oracle):
     a = oracle.solve(w, x0, 9, 1.0 / (2 * n))
     b = oracle.solve_momentum(w, x0, 9, 1.0 / (2 * n), 0.0)
     assert numpy.array_equal(a[0], b[0]) and numpy.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_multicore_baseline_equals_scalar_oracle(oracle, threads):
+    """oracle/bb_oracle_mt.c (bench.py's multi-core cpu_baseline) runs the same
+    iteration as bbo_solve; only the order of the sums differs."""
+    n = 257
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    w[5, 9] = w[9, 5] = 0.0                       # a missing pair
+    x0 = _oracle.noisy_init(xs)
+    X1, h1 = oracle.solve(w, x0, 6, 1.0 / (2 * n))
+    Xt, ht = _oracle.solve_mt(w, x0, 6, 1.0 / (2 * n), threads)
+    assert numpy.abs(Xt - X1).max() < 1e-12 * numpy.abs(X1).max()
+    assert numpy.abs(ht / h1 - 1).max() < 1e-12
+    Xt2, ht2 = _oracle.solve_mt(w, x0, 6, 1.0 / (2 * n), threads)
+    assert numpy.array_equal(Xt, Xt2) and numpy.array_equal(ht, ht2)   # reproducible
