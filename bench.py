@@ -63,6 +63,24 @@ def random_walk(n, seed=0):
     return x - x.mean(axis=0)
 
 
+def host_cores():
+    """Host cores this process should use for the CPU baseline: its affinity mask,
+    cut to the cgroup's CPU quota if there is one, and to 16 -- the CPU share of a
+    one-GPU box of this pool (more threads than that only time-slice)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cores, 16))
+
+
 def cpu_baseline(n, iters):
     """The oracle's C loop on a bounded sample of the same workload shape, on the
     host cores of this box: oracle/bb_oracle_mt.c (OpenMP, every core this process
@@ -86,13 +104,14 @@ def cpu_baseline(n, iters):
     out = {"value": one, "unit": "Gpair-updates/s", "cores": 1, "kind": "port",
            "sample": "oracle bbo_solve, N=%d dense, %d iterations, %.1f s, gcc -O2, 1 thread"
                      % (n, it1, dt1)}
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     if cores > 1:
         try:
-            itm = iters * max(1, cores // 2)      # about as long as the scalar leg x2
+            _oracle.solve_mt(w, x0, 2, 1.0 / (2 * n), cores, f64=False)     # threads, pages
+            t0 = time.perf_counter()
+            _oracle.solve_mt(w, x0, 4, 1.0 / (2 * n), cores, f64=False)     # sizes the sample
+            per_iter = (time.perf_counter() - t0) / 4
+            itm = int(min(max(8.0 / per_iter, 4), 100 * iters))            # about 8 s
             t0 = time.perf_counter()
             _oracle.solve_mt(w, x0, itm, 1.0 / (2 * n), cores, f64=False)
             dtm = time.perf_counter() - t0
