@@ -83,3 +83,116 @@ def test_sharded_solve_equals_single_process_oracle(oracle, world, dtype):
     # every rank applied the identical update: replicas are bit-identical
     for rank, X, hist, _ in results[1:]:
         assert numpy.array_equal(X, results[0][1]) and numpy.array_equal(hist, results[0][2])
+
+
+# ---- select_exchange: the decision logic, with a scripted engine -----------------
+class _ScriptedEngine(object):
+    """Stands in for HipEngine: records what select_exchange does to it and lets a
+    test script how each transport behaves (no GPU, no RCCL)."""
+
+    def __init__(self, peer_ok=True, rccl_ok=True, peer_shift=0.0, peer_raises=False,
+                 peer_sleep=0.0, rccl_sleep=0.0):
+        self.world, self.rank = 1, 0
+        self.x = numpy.arange(12.0).reshape(4, 3)
+        self.calls = []
+        self._comm_state = None
+        self._comm_trial = None
+        self.peer_ok, self.rccl_ok = peer_ok, rccl_ok
+        self.peer_shift, self.peer_raises = peer_shift, peer_raises
+        self.peer_sleep, self.rccl_sleep = peer_sleep, rccl_sleep
+        self._peer_error = "scripted"
+
+    def peer_setup(self):
+        return self.peer_ok
+
+    def comm_setup(self):
+        return self.rccl_ok
+
+    def get_coords(self):
+        return self.x.copy()
+
+    def set_coords(self, x):
+        self.x = numpy.array(x, dtype=float)
+        self.calls.append("set_coords")
+
+    def sync(self):
+        pass
+
+    def peer_status(self):
+        if self.peer_raises:
+            raise RuntimeError("peer exchange: time limit")
+        return 0
+
+    def iterate_dist(self, k, lr):
+        import time
+        time.sleep(self.rccl_sleep * k)
+        self.x = self.x - lr * k
+        self.calls.append("rccl")
+
+    def iterate_peer(self, k, lr):
+        import time
+        time.sleep(self.peer_sleep * k)
+        self.x = self.x - lr * k * (1.0 + self.peer_shift)
+        self.calls.append("peer")
+
+
+@pytest.fixture
+def one_rank_group(monkeypatch):
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(port))
+    monkeypatch.delenv("BB_COMM", raising=False)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kwargs,expect", [
+    (dict(peer_sleep=0.0, rccl_sleep=0.002), "peer"),          # agrees and is faster
+    (dict(peer_sleep=0.002, rccl_sleep=0.0), "rccl"),          # agrees but is slower
+    (dict(peer_shift=0.1, rccl_sleep=0.002), "rccl"),          # faster but WRONG
+    (dict(peer_raises=True, rccl_sleep=0.002), "rccl"),        # a wait timed out
+    (dict(peer_ok=False), "rccl"),                             # arenas could not be mapped
+    (dict(peer_ok=False, rccl_ok=False), "torch"),             # neither
+])
+def test_select_exchange_auto_is_a_measured_validated_choice(one_rank_group, monkeypatch, kwargs,
+                                                             expect):
+    from blueberry_amd import solver
+    monkeypatch.setattr(one_rank_group, "get_backend", lambda *a, **k: "nccl")
+    e = _ScriptedEngine(**kwargs)
+    x0 = e.get_coords()
+    assert solver.select_exchange(e, 0.5) == expect
+    assert e._comm_state == expect
+    assert numpy.array_equal(e.get_coords(), x0)               # the start is restored
+    if kwargs.get("peer_ok", True) and kwargs.get("rccl_ok", True):
+        agree = not kwargs.get("peer_shift") and not kwargs.get("peer_raises")
+        assert e._comm_trial["agree"] == agree
+    assert solver.select_exchange(e, 0.5) == expect            # decided once
+
+
+def test_select_exchange_overrides(one_rank_group, monkeypatch):
+    from blueberry_amd import solver
+    monkeypatch.setattr(one_rank_group, "get_backend", lambda *a, **k: "nccl")
+    for want, kwargs, expect in (("peer", {}, "peer"), ("rccl", {}, "rccl"),
+                                 ("rccl", dict(rccl_ok=False), "torch"), ("torch", {}, "torch"),
+                                 ("host", {}, "host")):
+        monkeypatch.setenv("BB_COMM", want)
+        e = _ScriptedEngine(**kwargs)
+        assert solver.select_exchange(e, 0.5) == expect
+        assert e.calls == []                                   # no trial when the choice is forced
+    monkeypatch.setenv("BB_COMM", "peer")
+    with pytest.raises(RuntimeError, match="could not be set up"):
+        solver.select_exchange(_ScriptedEngine(peer_ok=False), 0.5)
+    monkeypatch.setenv("BB_COMM", "bogus")
+    with pytest.raises(ValueError):
+        solver.select_exchange(_ScriptedEngine(), 0.5)
+
+
+def test_select_exchange_on_gloo_is_host_staged(one_rank_group):
+    from blueberry_amd import solver
+    e = _ScriptedEngine()
+    assert solver.select_exchange(e, 0.5) == "host" and e.calls == []
