@@ -617,22 +617,40 @@ def select_exchange(eng, lr, trial=True):
             runs = {}
             for name, step in (("rccl", eng.iterate_dist), ("peer", eng.iterate_peer)):
                 eng.set_coords(x0)
-                ok = True
-                try:
+                ok, x1, dt = True, None, float("inf")
+
+                def attempt(fn):
+                    # a transport that fails here is just not used; the collectives
+                    # between the attempts are still entered by every rank
+                    try:
+                        return fn()
+                    except Exception as exc:
+                        eng._comm_trial_error = "%s: %s" % (name, exc)
+                        return None
+
+                def warm():
                     step(1, lr)
-                    x1 = eng.get_coords()
+                    x = eng.get_coords()
                     step(3, lr)
                     eng.sync()
-                    dist.barrier()
+                    return x
+
+                def timed():
                     t0 = time.perf_counter()
                     step(10, lr)
                     eng.sync()
-                    dt = (time.perf_counter() - t0) / 10
+                    t = (time.perf_counter() - t0) / 10
                     if name == "peer":
                         eng.peer_status()
-                except Exception as exc:       # a transport that fails here is just not used
-                    ok, x1, dt = False, None, float("inf")
-                    eng._comm_trial_error = "%s: %s" % (name, exc)
+                    return t
+
+                x1 = attempt(warm)
+                dist.barrier()
+                t = attempt(timed) if x1 is not None else None
+                if x1 is None or t is None:
+                    ok, x1 = False, None
+                else:
+                    dt = t
                 runs[name] = (ok, x1, dt)
             eng.set_coords(x0)
             agree = bool(runs["rccl"][0] and runs["peer"][0] and numpy.allclose(
