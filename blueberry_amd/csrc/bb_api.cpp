@@ -56,11 +56,11 @@ int bb_layout_dense_info(int64_t n_bins, int dtype, bb_layout_info *info) {
     BB_REQUIRE(info != nullptr, "bb_layout_dense_info: info is NULL");
     BB_REQUIRE(n_bins >= 1, "bb_layout_dense_info: n_bins must be >= 1");
     BB_REQUIRE(dtype == BB_F32 || dtype == BB_F64, "bb_layout_dense_info: bad dtype");
-    const int64_t vw = bb::tile_width(dtype);
+    const int64_t vw = bb::tile_width(dtype, n_bins);
     info->n_bins = n_bins;
     info->vw = vw;
     info->n_pad = bb::round_up(n_bins, vw);
-    info->rows_per_unit = bb::rows_per_unit(dtype);
+    info->rows_per_unit = bb::rows_per_unit(dtype, n_bins);
     info->units_per_tile = vw / info->rows_per_unit;
     info->n_blocks = info->n_pad / vw;
     info->n_tiles = info->n_blocks * (info->n_blocks + 1) / 2;

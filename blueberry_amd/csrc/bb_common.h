@@ -29,12 +29,21 @@ int fail(int code, const std::string &msg);
 
 // ---- layout constants (docs/SPEC.md 3) -----------------------------------
 // A unit is always 8 KiB = 8 wave-loads of 64 lanes x 16 B.
-//   fp32: 4 matrix rows x 512 columns (2 loads per row); fp64: 8 rows x 128 columns.
+//   fp32: 4 matrix rows x 512 columns (2 loads per row)
+//   fp64: 2 rows x 512 columns (4 loads per row) above kF64WideFrom bins, where the
+//         sweep is what matters; 8 rows x 128 columns (1 load per row) up to it,
+//         where small column partials and many blocks matter (launch-bound regime).
+// Crossover measured on MI355X: N=2,500 is 24 us per iteration narrow / 30 wide,
+// N=6,000 is 64 narrow / 52 wide.
 constexpr int kUnitBytes = 8192;
+constexpr int64_t kF64WideFrom = 4096;
 
 inline int64_t elem_size(int dtype) { return dtype == BB_F64 ? 8 : 4; }
-inline int64_t tile_width(int dtype) { return dtype == BB_F64 ? 128 : 512; }
-inline int64_t rows_per_unit(int dtype) { return dtype == BB_F64 ? 8 : 4; }
+inline bool wide_layout(int dtype, int64_t n_bins) { return dtype != BB_F64 || n_bins > kF64WideFrom; }
+inline int64_t tile_width(int dtype, int64_t n_bins) { return wide_layout(dtype, n_bins) ? 512 : 128; }
+inline int64_t rows_per_unit(int dtype, int64_t n_bins) {
+    return dtype != BB_F64 ? 4 : (wide_layout(dtype, n_bins) ? 2 : 8);
+}
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 // Select the device, failing loudly when there is none.

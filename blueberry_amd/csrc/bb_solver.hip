@@ -5,10 +5,11 @@
 // Specification: docs/SPEC.md (build-authored; the reference has no solver,
 // SURVEY.md section 0).  Data layout and kernel design: DESIGN.md 3-4.
 //
-// Layout recap (SPEC 3).  The matrix is cut into vw x vw tiles (vw = 512 fp32 /
-// 128 fp64 columns), upper-triangular tiles only, ordered column-strip major
-// (J, then I).  A tile is vw/rpu "units"; a unit is rpu matrix rows x vw
-// columns = 8 KiB, row-major (fp32: 4 rows of 2 KiB; fp64: 8 rows of 1 KiB).
+// Layout recap (SPEC 3).  The matrix is cut into vw x vw tiles (vw = 512 columns;
+// 128 for small fp64 problems, see Lay<> below), upper-triangular tiles only, ordered
+// column-strip major (J, then I).  A tile is vw/rpu "units"; a unit is rpu matrix rows
+// x vw columns = 8 KiB, row-major (fp32: 4 rows of 2 KiB; fp64: 2 rows of 4 KiB, or 8
+// rows of 1 KiB).
 // One wave reads a matrix row of a unit with LPR 16-B-per-lane loads and lane
 // l always owns the same LPR*VPL columns of the strip.  That makes the column
 // side of the symmetric update register-resident for a whole strip sweep (no
@@ -38,19 +39,46 @@ template <>
 struct Traits<float> {
     using Vec = float4;
     static constexpr int VPL = 4;  // elements per lane per 16-B load
-    static constexpr int LPR = 2;  // 16-B loads per lane per matrix row
-    static constexpr int VW = 512; // columns of a strip = 64 * VPL * LPR
-    static constexpr int RPU = 4;  // matrix rows per 8-KiB unit
     static __device__ __forceinline__ float eps2() { return 1e-30f; }
 };
 template <>
 struct Traits<double> {
     using Vec = double2;
     static constexpr int VPL = 2;
-    static constexpr int LPR = 1;
-    static constexpr int VW = 128;
-    static constexpr int RPU = 8;
     static __device__ __forceinline__ double eps2() { return 1e-300; }
+};
+
+// Shape of a unit (8 KiB = 8 wave-loads) and of a strip.  LPR 16-byte loads per lane
+// and matrix row, VW = 64 * VPL * LPR columns per strip, RPU = 8 / LPR matrix rows.
+//   fp32          4 rows x 512 columns: 8 pairs per lane and row, packed math
+//   fp64 wide     2 rows x 512 columns: also 8 pairs per lane and row, so the DPP
+//                 reduction, the row-coordinate fetch and the row-sum stores are
+//                 amortised over 4x more pairs than in the narrow shape (+40 % at
+//                 N=20k); 96 VGPRs of column state, so at most 2 waves per SIMD
+//   fp64 narrow   8 rows x 128 columns: 4x smaller column partials and 4x more
+//                 blocks for the reduce -- what small problems want (N=963: 14.5 us
+//                 per iteration against 26 us in the wide shape); bb_common.h picks
+//                 it for n_bins <= kF64WideFrom
+template <typename T, bool W>
+struct Lay;
+template <bool W>
+struct Lay<float, W> {
+    static constexpr int LPR = 2, VW = 512, RPU = 4;
+    static constexpr int MIN_WG = 4;            // __launch_bounds__: <= 128 VGPRs
+    static constexpr bool SCALAR_XROW = true;   // 12 row coordinates through the scalar cache
+};
+template <>
+struct Lay<double, true> {
+    static constexpr int LPR = 4, VW = 512, RPU = 2;
+    static constexpr int MIN_WG = 2;            // <= 256 VGPRs
+    static constexpr bool SCALAR_XROW = true;   // 6 doubles = 12 SGPRs, double-buffered
+};
+template <>
+struct Lay<double, false> {
+    static constexpr int LPR = 1, VW = 128, RPU = 8;
+    static constexpr int MIN_WG = 4;
+    static constexpr bool SCALAR_XROW = false;  // 24 doubles x 2 would not fit the SGPR file:
+                                                // one per-lane load + v_readlane instead
 };
 
 template <int C>
@@ -233,35 +261,39 @@ __device__ __forceinline__ double2 stream_load(const double2 *p) {
     }
 }
 
-// One unit (8 matrix rows).  Row r of the CURRENT unit is consumed from d[r],
-// then d[r] is immediately refilled with row r of the NEXT unit, so 8 KiB per
-// wave stay in flight with a single 8-row register buffer.
-template <typename T, bool NT, int OP>
-__device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[Traits<T>::RPU], T xrow,
+// One unit, generic (fp64) form: RPU matrix rows of LPR wave-loads each.  Load k of
+// row r of the CURRENT unit is consumed from d[r*LPR + k], which is then refilled at
+// once with the same load of the NEXT unit, so 8 KiB per wave stay in flight with a
+// single register window.  xrow.get(q): the unit's q-th row coordinate, wave-uniform.
+template <typename T, bool W, bool NT, int OP, typename XR>
+__device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[8], const XR &xrow,
                                              const typename Traits<T>::Vec *__restrict__ next,
-                                             const T (&xj)[Traits<T>::VPL][3],
-                                             T (&gc)[Traits<T>::VPL][3], double &stress,
-                                             __amdgpu_buffer_rsrc_t row_rsrc, unsigned row_voff) {
-    constexpr int VPL = Traits<T>::VPL;
-    static_assert(Traits<T>::LPR == 1, "generic path: one load per matrix row");
+                                             const T (&xj)[(Lay<T, W>::LPR)][Traits<T>::VPL][3],
+                                             T (&gc)[(Lay<T, W>::LPR)][Traits<T>::VPL][3],
+                                             double &stress, __amdgpu_buffer_rsrc_t row_rsrc,
+                                             unsigned row_voff) {
+    constexpr int VPL = Traits<T>::VPL, LPR = Lay<T, W>::LPR;
+    static_assert(Lay<T, W>::RPU * LPR == 8, "a unit is 8 wave-loads");
     T s = T(0);
 #pragma unroll
-    for (int r = 0; r < Traits<T>::RPU; ++r) {
-        const T xi = lane_value(xrow, 3 * r), yi = lane_value(xrow, 3 * r + 1),
-                zi = lane_value(xrow, 3 * r + 2);
+    for (int r = 0; r < Lay<T, W>::RPU; ++r) {
+        const T xi = xrow.get(3 * r), yi = xrow.get(3 * r + 1), zi = xrow.get(3 * r + 2);
         T gx = T(0), gy = T(0), gz = T(0);
-        pair_step<T, 0, OP>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
-        pair_step<T, 1, OP>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
-        if constexpr (VPL == 4) {
-            pair_step<T, 2, OP>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
-            pair_step<T, 3, OP>(d[r], xi, yi, zi, xj, gc, gx, gy, gz, s);
+#pragma unroll
+        for (int k = 0; k < LPR; ++k) {
+            pair_step<T, 0, OP>(d[r * LPR + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
+            pair_step<T, 1, OP>(d[r * LPR + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
+            if constexpr (VPL == 4) {
+                pair_step<T, 2, OP>(d[r * LPR + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
+                pair_step<T, 3, OP>(d[r * LPR + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
+            }
+            d[r * LPR + k] = stream_load<NT>(next + (r * LPR + k) * 64);
         }
-        d[r] = stream_load<NT>(next + r * 64);
         wave_sum_hi3(gx, gy, gz);
         // one 3-element store per matrix row, from the lane holding the sums
         store_row3(row_rsrc, row_voff + r * 3 * (unsigned)sizeof(T), gx, gy, gz);
-        // keep the rows in program order: otherwise the scheduler interleaves all
-        // eight rows for ILP and spills
+        // keep the rows in program order: otherwise the scheduler interleaves the
+        // rows for ILP and spills
         __builtin_amdgcn_sched_barrier(0);
     }
     stress += (double)s;
@@ -415,44 +447,53 @@ __device__ __forceinline__ const typename Traits<T>::Vec *unit_ptr(const T *__re
 }
 
 // coordinates of a unit's rows: 3*RPU consecutive elements, one per lane
-template <typename T>
+template <typename T, bool W>
 __device__ __forceinline__ T load_xrow(const T *__restrict__ X, int i0, int lane) {
-    return X[(int64_t)i0 * 3 + (lane < 3 * Traits<T>::RPU ? lane : 0)];
+    return X[(int64_t)i0 * 3 + (lane < 3 * Lay<T, W>::RPU ? lane : 0)];
 }
 
-template <typename T>
-__device__ __forceinline__ void load_strip(T (&xj)[Traits<T>::VPL][3], const T *__restrict__ X,
-                                           int j0, int lane) {
+// Generic (fp64) column-strip state: load k of a row brings columns
+// k*64*VPL + lane*VPL .. +VPL-1, so lane l owns 3*VPL consecutive coordinates per k.
+template <typename T, bool W>
+__device__ __forceinline__ void load_strip(T (&xj)[(Lay<T, W>::LPR)][Traits<T>::VPL][3],
+                                           const T *__restrict__ X, int j0, int lane) {
     using Vec = typename Traits<T>::Vec;
     constexpr int VPL = Traits<T>::VPL;
-    // 3*VPL consecutive elements (48 B) per lane
-    const Vec *p = reinterpret_cast<const Vec *>(X + ((int64_t)j0 + (int64_t)lane * VPL) * 3);
-    Vec a = p[0], b = p[1], c = p[2];
-    if constexpr (VPL == 4) {
-        xj[0][0] = a.x; xj[0][1] = a.y; xj[0][2] = a.z;
-        xj[1][0] = a.w; xj[1][1] = b.x; xj[1][2] = b.y;
-        xj[2][0] = b.z; xj[2][1] = b.w; xj[2][2] = c.x;
-        xj[3][0] = c.y; xj[3][1] = c.z; xj[3][2] = c.w;
-    } else {
-        xj[0][0] = a.x; xj[0][1] = a.y; xj[0][2] = b.x;
-        xj[1][0] = b.y; xj[1][1] = c.x; xj[1][2] = c.y;
+#pragma unroll
+    for (int k = 0; k < Lay<T, W>::LPR; ++k) {
+        const Vec *p = reinterpret_cast<const Vec *>(
+            X + ((int64_t)j0 + k * 64 * VPL + (int64_t)lane * VPL) * 3);
+        Vec a = p[0], b = p[1], c = p[2];
+        if constexpr (VPL == 4) {
+            xj[k][0][0] = a.x; xj[k][0][1] = a.y; xj[k][0][2] = a.z;
+            xj[k][1][0] = a.w; xj[k][1][1] = b.x; xj[k][1][2] = b.y;
+            xj[k][2][0] = b.z; xj[k][2][1] = b.w; xj[k][2][2] = c.x;
+            xj[k][3][0] = c.y; xj[k][3][1] = c.z; xj[k][3][2] = c.w;
+        } else {
+            xj[k][0][0] = a.x; xj[k][0][1] = a.y; xj[k][0][2] = b.x;
+            xj[k][1][0] = b.y; xj[k][1][1] = c.x; xj[k][1][2] = c.y;
+        }
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void store_strip(const T (&gc)[Traits<T>::VPL][3],
+template <typename T, bool W>
+__device__ __forceinline__ void store_strip(const T (&gc)[(Lay<T, W>::LPR)][Traits<T>::VPL][3],
                                             T *__restrict__ slot, int lane) {
     using Vec = typename Traits<T>::Vec;
     constexpr int VPL = Traits<T>::VPL;
-    Vec *p = reinterpret_cast<Vec *>(slot + (int64_t)lane * VPL * 3);
-    if constexpr (VPL == 4) {
-        p[0] = make_float4(gc[0][0], gc[0][1], gc[0][2], gc[1][0]);
-        p[1] = make_float4(gc[1][1], gc[1][2], gc[2][0], gc[2][1]);
-        p[2] = make_float4(gc[2][2], gc[3][0], gc[3][1], gc[3][2]);
-    } else {
-        p[0] = make_double2(gc[0][0], gc[0][1]);
-        p[1] = make_double2(gc[0][2], gc[1][0]);
-        p[2] = make_double2(gc[1][1], gc[1][2]);
+#pragma unroll
+    for (int k = 0; k < Lay<T, W>::LPR; ++k) {
+        Vec *p = reinterpret_cast<Vec *>(slot + ((int64_t)k * 64 * VPL + (int64_t)lane * VPL) * 3);
+        const auto &g = gc[k];
+        if constexpr (VPL == 4) {
+            p[0] = make_float4(g[0][0], g[0][1], g[0][2], g[1][0]);
+            p[1] = make_float4(g[1][1], g[1][2], g[2][0], g[2][1]);
+            p[2] = make_float4(g[2][2], g[3][0], g[3][1], g[3][2]);
+        } else {
+            p[0] = make_double2(g[0][0], g[0][1]);
+            p[1] = make_double2(g[0][2], g[1][0]);
+            p[2] = make_double2(g[1][1], g[1][2]);
+        }
     }
 }
 
@@ -470,14 +511,14 @@ __device__ __forceinline__ void store_strip(const T (&gc)[Traits<T>::VPL][3],
 //   rowpart    3*RPU elements per unit, base shifted to the rank's first tile
 //   colpart    3*VW elements per slot
 //   stresspart one double per wave
-template <typename T, bool NT, int OP>
-__global__ __launch_bounds__(256, 4) void stress_grad_kernel(
+template <typename T, bool W, bool NT, int OP>
+__global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
     const T *__restrict__ units, const T *__restrict__ X, const int2 *__restrict__ udesc,
     const int2 *__restrict__ wave_range, const int32_t *__restrict__ wave_slot,
     T *__restrict__ rowpart, T *__restrict__ colpart, double *__restrict__ stresspart) {
     using Vec = typename Traits<T>::Vec;
     constexpr int VPL = Traits<T>::VPL;
-    constexpr int VW = Traits<T>::VW;
+    constexpr int VW = Lay<T, W>::VW;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int2 range = wave_range[w];
@@ -488,47 +529,56 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
         int slot = wave_slot[w];
         Vec d[8];  // the unit's 8 wave-loads (8 KiB), in memory order
         // column-strip state: coordinates + gradient accumulators of this lane's columns
-        struct Generic { T xj[VPL][3], gc[VPL][3]; };
+        struct Generic { T xj[(Lay<T, W>::LPR)][VPL][3], gc[(Lay<T, W>::LPR)][VPL][3]; };
         using Strip = typename std::conditional<sizeof(T) == 4, StripF32, Generic>::type;
         Strip st;
         auto strip_load = [&](int j0) __attribute__((always_inline)) {
             if constexpr (sizeof(T) == 4) {
                 load_strip_f32(st, X, j0, lane);
             } else {
-                load_strip<T>(st.xj, X, j0, lane);
+                load_strip<T, W>(st.xj, X, j0, lane);
 #pragma unroll
-                for (int c = 0; c < VPL; ++c) st.gc[c][0] = st.gc[c][1] = st.gc[c][2] = T(0);
+                for (int k = 0; k < Lay<T, W>::LPR; ++k)
+#pragma unroll
+                    for (int c = 0; c < VPL; ++c)
+                        st.gc[k][c][0] = st.gc[k][c][1] = st.gc[k][c][2] = T(0);
             }
         };
         auto strip_store = [&](int sl) __attribute__((always_inline)) {
             if constexpr (sizeof(T) == 4)
                 store_strip_f32(st, colpart + (int64_t)sl * (3 * VW), lane);
             else
-                store_strip<T>(st.gc, colpart + (int64_t)sl * (3 * VW), lane);
+                store_strip<T, W>(st.gc, colpart + (int64_t)sl * (3 * VW), lane);
         };
 
         int2 dc = udesc[ua];                                   // current unit
         int2 dn = udesc[ua + 1 < ub ? ua + 1 : ua];            // next unit
         // Prologue: the x rows of the first unit, then its 8 matrix rows.
-        // Row coordinates of a unit.  fp32: 12 wave-uniform scalars fetched through
-        // the scalar cache (X is read-only in this kernel), one unit ahead -- no
-        // VMEM slot, no v_readlane.  fp64: one per-lane load + v_readlane (24
-        // doubles, double-buffered, would not fit the SGPR file).
-        struct XRowS { float v[12]; };
-        struct XRowV { T v; };
+        // Row coordinates of a unit, one unit ahead.  XRowS: 3*RPU wave-uniform scalars
+        // fetched through the scalar cache (X is read-only in this kernel) -- no VMEM
+        // slot, no v_readlane (12 floats or 6 doubles: 12 SGPRs, double-buffered).
+        // XRowV (fp64 narrow: 24 doubles): one per-lane load, v_readlane per use.
+        struct XRowS {
+            T v[3 * Lay<T, W>::RPU];
+            __device__ __forceinline__ T get(int q) const { return v[q]; }
+        };
+        struct XRowV {
+            T v;
+            __device__ __forceinline__ T get(int q) const { return lane_value(v, q); }
+        };
 #ifdef BB_ABL_XROW_VECTOR
         using XRow = XRowV;
 #else
-        using XRow = typename std::conditional<sizeof(T) == 4, XRowS, XRowV>::type;
+        using XRow = typename std::conditional<Lay<T, W>::SCALAR_XROW, XRowS, XRowV>::type;
 #endif
         auto xrow_load = [&](int i0) __attribute__((always_inline)) {
             XRow x;
             if constexpr (std::is_same<XRow, XRowS>::value) {
-                const float *px = reinterpret_cast<const float *>(X) + (int64_t)i0 * 3;
+                const T *px = X + (int64_t)i0 * 3;
 #pragma unroll
-                for (int q = 0; q < 12; ++q) x.v[q] = px[q];
+                for (int q = 0; q < 3 * Lay<T, W>::RPU; ++q) x.v[q] = px[q];
             } else {
-                x.v = load_xrow<T>(X, i0, lane);
+                x.v = load_xrow<T, W>(X, i0, lane);
             }
             return x;
         };
@@ -539,9 +589,9 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
             for (int r = 0; r < 8; ++r) d[r] = stream_load<NT>(first + r * 64);
         }
         // this wave's row partials: 3*RPU elements per unit of its group's chunk
-        constexpr unsigned kRowBytes = 3 * Traits<T>::RPU * sizeof(T);
+        constexpr unsigned kRowBytes = 3 * Lay<T, W>::RPU * sizeof(T);
         const __amdgpu_buffer_rsrc_t row_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            rowpart + (int64_t)ua * (3 * Traits<T>::RPU), 0, (int)((unsigned)(ub - ua) * kRowBytes),
+            rowpart + (int64_t)ua * (3 * Lay<T, W>::RPU), 0, (int)((unsigned)(ub - ua) * kRowBytes),
             0x00020000);
 
         auto unit_step = [&](int u) __attribute__((always_inline)) {
@@ -569,8 +619,8 @@ __global__ __launch_bounds__(256, 4) void stress_grad_kernel(
 #endif
             }
             else
-                process_unit<T, NT, OP>(d, xr.v, unit_ptr<T>(units, un, lane), st.xj, st.gc, stress,
-                                    row_rsrc, row_voff);
+                process_unit<T, W, NT, OP>(d, xr, unit_ptr<T>(units, un, lane), st.xj, st.gc, stress,
+                                       row_rsrc, row_voff);
             xr = xrn;
             dc = dn;
             dn = dnn;
@@ -649,9 +699,9 @@ struct ReduceParams {
     T lr;
 };
 
-template <typename T>
+template <typename T, bool W>
 __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
-    constexpr int CH = 3 * Traits<T>::VW;
+    constexpr int CH = 3 * Lay<T, W>::VW;
     constexpr int NE = (CH + 255) / 256;
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -664,10 +714,12 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
         // Chunks are summed in list order (deterministic).  A whole slice of up to
         // kReduceSlice chunks is loaded before the first add, so a slice costs one
         // memory round trip, not one per chunk: this kernel is latency-bound.
-        for (int64_t k = k0; k < k1; k += kReduceSlice) {
-            T v[kReduceSlice][NE];
+        // (fp64: half as many chunks per round trip, for the same 96 VGPRs of loads)
+        constexpr int kBatch = kReduceSlice * 4 / (int)sizeof(T);
+        for (int64_t k = k0; k < k1; k += kBatch) {
+            T v[kBatch][NE];
 #pragma unroll
-            for (int q = 0; q < kReduceSlice; ++q) {
+            for (int q = 0; q < kBatch; ++q) {
                 const bool on = k + q < k1;
                 const T *src = p.part + p.blk_chunk[on ? k + q : k0];
 #pragma unroll
@@ -677,7 +729,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
                 }
             }
 #pragma unroll
-            for (int q = 0; q < kReduceSlice; ++q)
+            for (int q = 0; q < kBatch; ++q)
 #pragma unroll
                 for (int j = 0; j < NE; ++j) acc[j] += v[q][j];
         }
@@ -844,15 +896,15 @@ __global__ __launch_bounds__(256) void apply_kernel(T *__restrict__ X, T *__rest
 // packing kernels
 // --------------------------------------------------------------------------
 // staged fp64 rows (row-major, ld = VW) -> units of one run of tiles.
-template <typename T>
+template <typename T, bool W>
 __global__ __launch_bounds__(256) void convert_units_kernel(
     const double *__restrict__ stage, T *__restrict__ units_out, const int2 *__restrict__ udesc,
     int64_t ul0, int64_t stage_row0 /* global row of stage row 0 */, int64_t n_bins, int kind,
     double neg_inv_alpha) {
-    constexpr int VW = Traits<T>::VW;
+    constexpr int VW = Lay<T, W>::VW;
     const int64_t ul = ul0 + blockIdx.x;
     const int2 dsc = udesc[ul];
-    constexpr int RPU = Traits<T>::RPU;
+    constexpr int RPU = Lay<T, W>::RPU;
     T *out = units_out + ul * (RPU * VW);
     for (int e = threadIdx.x; e < RPU * VW; e += 256) {
         const int r = e / VW, c = e % VW;
@@ -876,14 +928,14 @@ __global__ __launch_bounds__(256) void convert_units_kernel(
 // Sparse (i, j, value) entries -> resident units (blocked-sparse input).  The
 // units were zeroed ("no constraint") first.  tilemap[I * n_blocks + J] is the
 // tile's index in the global list or -1.
-template <typename T>
+template <typename T, bool W>
 __global__ __launch_bounds__(256) void scatter_entries_kernel(
     const int64_t *__restrict__ rows, const int64_t *__restrict__ cols,
     const double *__restrict__ vals, int64_t nnz, const int32_t *__restrict__ tilemap,
     int64_t n_blocks, int64_t n_bins, int64_t u_begin, int64_t u_end, T *__restrict__ units,
     int kind, double neg_inv_alpha, const double *__restrict__ kr,
     const double *__restrict__ krexp, int *__restrict__ bad) {
-    constexpr int VW = Traits<T>::VW, RPU = Traits<T>::RPU, UPT = VW / RPU;
+    constexpr int VW = Lay<T, W>::VW, RPU = Lay<T, W>::RPU, UPT = VW / RPU;
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= nnz) return;
     int64_t i = rows[k], j = cols[k];
@@ -910,15 +962,15 @@ __global__ __launch_bounds__(256) void scatter_entries_kernel(
 }
 
 // delta_ij = |x*_i - x*_j| generated in place (synthetic inputs).
-template <typename T>
+template <typename T, bool W>
 __global__ __launch_bounds__(256) void gen_units_kernel(const double *__restrict__ xs,
                                                         T *__restrict__ units_out,
                                                         const int2 *__restrict__ udesc,
                                                         int64_t n_bins) {
-    constexpr int VW = Traits<T>::VW;
+    constexpr int VW = Lay<T, W>::VW;
     const int64_t ul = blockIdx.x;
     const int2 dsc = udesc[ul];
-    constexpr int RPU = Traits<T>::RPU;
+    constexpr int RPU = Lay<T, W>::RPU;
     T *out = units_out + ul * (RPU * VW);
     for (int e = threadIdx.x; e < RPU * VW; e += 256) {
         const int r = e / VW, c = e % VW;
@@ -982,6 +1034,7 @@ __global__ void T_to_f64_kernel(const T *__restrict__ in, double *__restrict__ o
 // --------------------------------------------------------------------------
 struct bb_solver {
     int dtype = BB_F32, device = 0, rank = 0, world = 1;
+    bool wide = true;  // unit shape (Lay<T, wide>): false only for small fp64 problems
     bb_layout_info L{};
     std::vector<int32_t> tile_I, tile_J;  // global tile list (device order)
     int64_t u_begin = 0, u_end = 0, n_local = 0;
@@ -1202,7 +1255,13 @@ int build_indices(bb_solver *s) {
     return BB_OK;
 }
 
-template <typename T>
+// (dtype, layout) -> template arguments.  F(float, wide), F(double, wide), F(double, narrow).
+#define BB_BY_LAYOUT(s, F, ...)                                          \
+    ((s)->dtype == BB_F32 ? F<float, true>(__VA_ARGS__)                  \
+                          : ((s)->wide ? F<double, true>(__VA_ARGS__)    \
+                                       : F<double, false>(__VA_ARGS__)))
+
+template <typename T, bool W>
 int launch_grad_t(bb_solver *s, int op, const void *x_in) {
     const T *units = (const T *)s->d_units;
     const T *X = (const T *)x_in;
@@ -1212,7 +1271,7 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
     T *colpart = (T *)s->d_part + s->rowpart_elems;
     const dim3 grid(s->n_waves / 4), block(256);
 #define BB_LAUNCH(NTV, OPV)                                                                     \
-    hipLaunchKernelGGL((stress_grad_kernel<T, NTV, OPV>), grid, block, 0, s->stream, units, X, \
+    hipLaunchKernelGGL((stress_grad_kernel<T, W, NTV, OPV>), grid, block, 0, s->stream, units, X, \
                        s->d_udesc, s->d_wave_range, s->d_wave_slot, rowpart, colpart,          \
                        s->d_stresspart)
     if (op == kOpMatvec2) {
@@ -1225,7 +1284,7 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
     return BB_OK;
 }
 
-template <typename T>
+template <typename T, bool W>
 int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, double scale) {
     ReduceParams<T> p;
     p.part = (const T *)s->d_part;
@@ -1254,26 +1313,24 @@ int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, doubl
         p.blk_ptr = s->d_s1_ptr;
         p.blk_chunk = s->d_s1_chunk;
         p.mode = kReducePartial;
-        hipLaunchKernelGGL(reduce_kernel<T>, dim3((unsigned)s->n_slices), dim3(256), 0, s->stream, p);
+        hipLaunchKernelGGL((reduce_kernel<T, W>), dim3((unsigned)s->n_slices), dim3(256), 0, s->stream, p);
         BB_HIP_CHECK(hipGetLastError());
     }
     p.blk_ptr = s->d_blk_ptr;
     p.blk_chunk = s->d_blk_chunk;
     p.mode = mode;
     const int grid = mode == kReduceStressOnly ? 1 : (int)s->L.n_blocks;
-    hipLaunchKernelGGL(reduce_kernel<T>, dim3(grid), dim3(256), 0, s->stream, p);
+    hipLaunchKernelGGL((reduce_kernel<T, W>), dim3(grid), dim3(256), 0, s->stream, p);
     BB_HIP_CHECK(hipGetLastError());
     return BB_OK;
 }
 
 int launch_grad(bb_solver *s, int op = kOpStress, const void *x_in = nullptr) {
     if (!x_in) x_in = s->d_X;
-    return s->dtype == BB_F32 ? launch_grad_t<float>(s, op, x_in)
-                              : launch_grad_t<double>(s, op, x_in);
+    return BB_BY_LAYOUT(s, launch_grad_t, s, op, x_in);
 }
 int launch_reduce(bb_solver *s, int mode, double lr, double *stress_out, double scale = 2.0) {
-    return s->dtype == BB_F32 ? launch_reduce_t<float>(s, mode, lr, stress_out, scale)
-                              : launch_reduce_t<double>(s, mode, lr, stress_out, scale);
+    return BB_BY_LAYOUT(s, launch_reduce_t, s, mode, lr, stress_out, scale);
 }
 
 hipEvent_t *timing_slot(bb_solver *s) {
@@ -1293,9 +1350,9 @@ int check_ready(const bb_solver *s, const char *who) {
     return BB_OK;
 }
 
-template <typename T>
+template <typename T, bool W>
 int set_wish_dense_t(bb_solver *s, const double *host, int64_t ld, int kind, double alpha) {
-    constexpr int VW = Traits<T>::VW;
+    constexpr int VW = Lay<T, W>::VW;
     const int64_t upt = s->L.units_per_tile, n = s->L.n_bins;
     constexpr int64_t kRunTiles = 4;  // tiles staged per copy
     double *stage = nullptr;
@@ -1325,7 +1382,7 @@ int set_wish_dense_t(bb_solver *s, const double *host, int64_t ld, int kind, dou
                                  (size_t)ld * sizeof(double), (size_t)cols_valid * sizeof(double),
                                  (size_t)rows_valid, hipMemcpyHostToDevice, s->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(convert_units_kernel<T>, dim3((unsigned)(ue - ul)), dim3(256), 0,
+            hipLaunchKernelGGL((convert_units_kernel<T, W>), dim3((unsigned)(ue - ul)), dim3(256), 0,
                                s->stream, stage, (T *)s->d_units, s->d_udesc, ul, i_start, n,
                                kind, -1.0 / alpha);
             e = hipGetLastError();
@@ -1403,6 +1460,7 @@ int bb_solver_create(bb_solver **out, int64_t n_bins, int dtype, int device, int
     s->rank = rank;
     s->world = world;
     int rc = bb_layout_dense_info(n_bins, dtype, &s->L);
+    s->wide = bb::wide_layout(dtype, n_bins);
     if (rc == BB_OK) {
         if (tile_I == nullptr) {
             s->tile_I.resize((size_t)s->L.n_tiles);
@@ -1505,8 +1563,7 @@ int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld, int k
                "bb_solver_set_wish_dense: bad kind");
     BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_dense: alpha must be > 0");
     BB_TRY(bb::enter_device(s->device));
-    int rc = s->dtype == BB_F32 ? set_wish_dense_t<float>(s, host, ld, kind, alpha)
-                                : set_wish_dense_t<double>(s, host, ld, kind, alpha);
+    int rc = BB_BY_LAYOUT(s, set_wish_dense_t, s, host, ld, kind, alpha);
     if (rc == BB_OK) s->have_wish = true;
     return rc;
 }
@@ -1562,16 +1619,14 @@ int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *
                 e = hipMemcpyAsync(d_vals, vals + k0, (size_t)m * 8, hipMemcpyHostToDevice, s->stream);
             if (e != hipSuccess) break;
             const unsigned grid = (unsigned)((m + 255) / 256);
-            if (s->dtype == BB_F32)
-                hipLaunchKernelGGL(scatter_entries_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
-                                   d_rows, d_cols, d_vals, m, d_map, nb, s->L.n_bins, s->u_begin,
-                                   s->u_end, (float *)s->d_units, kind, -1.0 / alpha, d_kr, d_ke,
-                                   d_bad);
-            else
-                hipLaunchKernelGGL(scatter_entries_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
-                                   d_rows, d_cols, d_vals, m, d_map, nb, s->L.n_bins, s->u_begin,
-                                   s->u_end, (double *)s->d_units, kind, -1.0 / alpha, d_kr, d_ke,
-                                   d_bad);
+#define BB_SCATTER(TT, WW)                                                                        \
+    hipLaunchKernelGGL((scatter_entries_kernel<TT, WW>), dim3(grid), dim3(256), 0, s->stream, d_rows, \
+                       d_cols, d_vals, m, d_map, nb, s->L.n_bins, s->u_begin, s->u_end,              \
+                       (TT *)s->d_units, kind, -1.0 / alpha, d_kr, d_ke, d_bad)
+            if (s->dtype == BB_F32) BB_SCATTER(float, true);
+            else if (s->wide) BB_SCATTER(double, true);
+            else BB_SCATTER(double, false);
+#undef BB_SCATTER
             e = hipGetLastError();
             // the staging buffers are reused by the next chunk: stream order makes that safe
         }
@@ -1606,14 +1661,13 @@ int bb_solver_set_wish_from_coords(bb_solver *s, const double *xstar) {
     BB_HIP_CHECK(hipMemcpyAsync(s->d_f64_tmp, xstar, (size_t)s->L.n_bins * 3 * sizeof(double),
                                 hipMemcpyHostToDevice, s->stream));
     if (s->n_local > 0) {
-        if (s->dtype == BB_F32)
-            hipLaunchKernelGGL(gen_units_kernel<float>, dim3((unsigned)s->n_local), dim3(256), 0,
-                               s->stream, s->d_f64_tmp, (float *)s->d_units, s->d_udesc,
-                               s->L.n_bins);
-        else
-            hipLaunchKernelGGL(gen_units_kernel<double>, dim3((unsigned)s->n_local), dim3(256), 0,
-                               s->stream, s->d_f64_tmp, (double *)s->d_units, s->d_udesc,
-                               s->L.n_bins);
+#define BB_GEN(TT, WW)                                                                          \
+    hipLaunchKernelGGL((gen_units_kernel<TT, WW>), dim3((unsigned)s->n_local), dim3(256), 0, s->stream, \
+                       s->d_f64_tmp, (TT *)s->d_units, s->d_udesc, s->L.n_bins)
+        if (s->dtype == BB_F32) BB_GEN(float, true);
+        else if (s->wide) BB_GEN(double, true);
+        else BB_GEN(double, false);
+#undef BB_GEN
         BB_HIP_CHECK(hipGetLastError());
     }
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));

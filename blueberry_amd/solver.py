@@ -318,10 +318,18 @@ def _check_coords(x, n_bins):
     return x
 
 
+def layout_info(n_bins, dtype):
+    """bb_layout_dense_info as a dict (host-only arithmetic: no GPU needed)."""
+    info = _lib.LayoutInfo()
+    _lib.check(_lib.load().bb_layout_dense_info(int(n_bins), _DTYPES[dtype], info),
+               "bb_layout_dense_info")
+    return info.as_dict()
+
+
 def tiles_from_entries(n_bins, rows, cols, dtype):
     """The (tile_I, tile_J) list -- device order: J ascending, then I -- of the
     tiles that hold at least one entry (rows[k], cols[k]); either triangle."""
-    vw = 512 if dtype == "float32" else 128
+    vw = layout_info(n_bins, dtype)["vw"]     # 512, or 128 for small fp64 problems
     r = numpy.asarray(rows, dtype=numpy.int64)
     c = numpy.asarray(cols, dtype=numpy.int64)
     if r.size and (min(r.min(), c.min()) < 0 or max(r.max(), c.max()) >= n_bins):

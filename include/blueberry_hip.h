@@ -77,8 +77,8 @@ BB_API int bb_band_count_rows(const double *regions, int64_t n, int32_t low, int
 typedef struct bb_layout_info {
     int64_t n_bins;         /* N                                              */
     int64_t n_pad;          /* N rounded up to a multiple of vw               */
-    int64_t vw;             /* tile edge = strip width: 512 (fp32), 128 (fp64)  */
-    int64_t rows_per_unit;  /* matrix rows per 8-KiB unit: 4 (fp32), 8 (fp64) */
+    int64_t vw;             /* tile edge = strip width: 512; fp64 <= 4096 bins: 128 */
+    int64_t rows_per_unit;  /* rows per 8-KiB unit: 4 (fp32); fp64: 2, or 8 when vw = 128 */
     int64_t units_per_tile; /* vw / rows_per_unit                             */
     int64_t n_blocks;       /* n_pad / vw                                     */
     int64_t n_tiles;        /* upper-triangular tiles incl. the diagonal      */

@@ -370,7 +370,7 @@ def test_solver_blocked_sparse_input(oracle, dtype, tol):
     assert _rel(s.structure_, X_ref) < tol
     # far fewer tiles than the dense triangle
     ti, tj = bb.solver.tiles_from_entries(n, r, c, dtype)
-    vw = 512 if dtype == "float32" else 128
+    vw = bb.solver.layout_info(n, dtype)["vw"]
     nb = -(-n // vw)
     assert len(ti) < nb * (nb + 1) // 2 or nb <= 5
     assert (ti <= tj).all()
@@ -734,3 +734,45 @@ def test_event_timing_every_kth_iteration():
     e.iterate(3, 1.0 / (2 * n))
     assert e.timing()["launches"] == 0      # switching resets; nothing recorded while off
     e.close()
+
+
+def test_fp64_wide_layout_vs_oracle(oracle):
+    """fp64 above 4096 bins switches to 2-row x 512-column units: the same
+    checks the narrow layout gets at small sizes -- solve with momentum, the sum of
+    rank shares, the matvec, a sparse tile list -- against the oracle at 1e-12."""
+    n, k, tol = 4300, 3, 1e-12
+    xs, w, x0 = _problem(n)
+    w[7, 4000] = w[4000, 7] = 0.0                           # a missing pair
+    lay = bb.solver.layout_info(n, "float64")
+    assert lay["vw"] == 512 and lay["rows_per_unit"] == 2
+    lr = 1.0 / (2 * n)
+    X_ref, h_ref = oracle.solve_momentum(w, x0, k, lr, 0.3)
+    s = bb.StructureSolver(n_iter=k, lr=lr, dtype="float64", kind="wish", momentum=0.3)
+    s.fit(w, init=x0)
+    assert numpy.abs(s.stress_ / h_ref - 1).max() < tol
+    assert _rel(s.structure_, X_ref) < tol
+    # three rank shares sum to the oracle's full gradient; matvec for the spectral start
+    s_ref, g_ref = oracle.stress_grad(w, x0)
+    x = numpy.random.default_rng(2).standard_normal((n, 3))
+    g_sum, s_sum, y_sum = numpy.zeros((n, 3)), 0.0, numpy.zeros((n, 3))
+    for rank in range(3):
+        e = HipEngine(n, "float64", rank=rank, world=3)
+        e.set_wish_dense(w, "wish", 3.0)
+        y_sum += e.matvec_sq(x)
+        e.set_coords(x0)
+        e.grad()
+        host = e.read_exchange()
+        g_sum += host[:3 * n].reshape(n, 3)
+        s_sum += float(host[-2]) + float(host[-1])
+        e.close()
+    assert abs(s_sum / s_ref - 1) < tol
+    assert numpy.abs(g_sum - g_ref).max() < tol * numpy.abs(g_ref).max()
+    want = (w * w) @ x
+    assert numpy.abs(y_sum - want).max() < tol * numpy.abs(want).max()
+    # blocked-sparse: a band of the same matrix through scipy.sparse
+    import scipy.sparse
+    band = numpy.triu(numpy.tril(w, 700), -700)
+    X_b, h_b = oracle.solve(band, x0, k, lr)
+    sp = bb.StructureSolver(n_iter=k, lr=lr, dtype="float64", kind="wish")
+    sp.fit(scipy.sparse.coo_matrix(band), init=x0)
+    assert numpy.abs(sp.stress_ / h_b - 1).max() < tol and _rel(sp.structure_, X_b) < tol

@@ -65,12 +65,15 @@ def test_compute_fails_loudly_without_gpu():
 
 
 # ---- layout ------------------------------------------------------------------
-@pytest.mark.parametrize("dtype,vw,rpu", [(_lib.BB_F32, 512, 4), (_lib.BB_F64, 128, 8)])
-@pytest.mark.parametrize("n", [1, 2, 127, 128, 129, 511, 512, 513, 963, 24926, 50000, 309568])
-def test_dense_layout(dtype, vw, rpu, n):
+@pytest.mark.parametrize("dtype", [_lib.BB_F32, _lib.BB_F64])
+@pytest.mark.parametrize("n", [1, 2, 127, 128, 129, 511, 512, 513, 963, 4096, 4097, 24926, 50000,
+                               309568])
+def test_dense_layout(dtype, n):
     lib = _lib.load()
     info = _lib.LayoutInfo()
     _lib.check(lib.bb_layout_dense_info(n, dtype, info))
+    # fp32: 4 rows x 512 columns per unit; fp64: 8 x 128 up to 4096 bins, 2 x 512 above
+    vw, rpu = (512, 4) if dtype == _lib.BB_F32 else ((128, 8) if n <= 4096 else (512, 2))
     assert info.vw == vw and info.rows_per_unit == rpu and info.units_per_tile == vw // rpu
     assert info.n_pad % vw == 0 and 0 <= info.n_pad - n < vw
     nb = info.n_pad // vw
@@ -282,8 +285,11 @@ def test_early_stop_with_tolerance():
 def test_tiles_from_entries_and_plot_smoke():
     from blueberry_amd.solver import tiles_from_entries
     ti, tj = tiles_from_entries(1300, [0, 1299, 600, 5], [1299, 0, 700, 5], "float64")
-    # vw = 128: pairs (0,1299)->tile (0,10) once, (600,700)->(4,5), (5,5)->(0,0); order (J, I)
+    # fp64, 1300 bins: vw = 128: pairs (0,1299)->tile (0,10) once, (600,700)->(4,5),
+    # (5,5)->(0,0); order (J, I)
     assert list(zip(ti.tolist(), tj.tolist())) == [(0, 0), (4, 5), (0, 10)]
+    ti, tj = tiles_from_entries(5000, [0, 4999, 600], [4999, 0, 700], "float64")   # wide: 512
+    assert list(zip(ti.tolist(), tj.tolist())) == [(1, 1), (0, 9)]
     ti32, tj32 = tiles_from_entries(1300, [0, 1299, 600, 5], [1299, 0, 700, 5], "float32")
     assert list(zip(ti32.tolist(), tj32.tolist())) == [(0, 0), (1, 1), (0, 2)]
     with pytest.raises(ValueError):
