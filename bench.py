@@ -212,6 +212,8 @@ def main():
 
     def fence():
         eng.sync()
+        if eng._comm_state == "peer":
+            eng.peer_status()                  # a timed-out exchange must not pass as a result
         if use_dist:
             torch.cuda.synchronize()
             dist.barrier()

@@ -516,6 +516,8 @@ class StructureSolver(object):
                     if h.size >= 2 and h[-2] > 0 and \
                             abs(h[-2] - h[-1]) <= self.tol * h[-2]:
                         break
+            if getattr(eng, "_comm_state", None) == "peer":
+                eng.peer_status()              # raises if a peer wait ran into its time limit
             self.structure_ = eng.get_coords()
             self.stress_ = eng.stress_history()
         finally:
