@@ -42,6 +42,15 @@ for n in sizes:
         rows.append("n=%6d %-6s step %.4f ms = kernel %.4f + reduce %.4f + rest %.4f" % (
             n, name, t["step_ms"], t["grad_ms"], t["reduce_ms"],
             t["step_ms"] - t["grad_ms"] - t["reduce_ms"]))
+        # the same without any timing events: host clock around 1000 enqueued iterations
+        e.set_timing(False)
+        import time
+        run_iterations(e, 50, 1.0 / (2 * n), world)
+        e.sync()
+        t0 = time.perf_counter()
+        run_iterations(e, 1000, 1.0 / (2 * n), world)
+        e.sync()
+        rows[-1] += "   | no events: %.4f ms per step" % ((time.perf_counter() - t0))
         e.close()
 os.dup2(fd, 1)
 print("\n".join(rows))
