@@ -776,3 +776,11 @@ def test_fp64_wide_layout_vs_oracle(oracle):
     sp = bb.StructureSolver(n_iter=k, lr=lr, dtype="float64", kind="wish")
     sp.fit(scipy.sparse.coo_matrix(band), init=x0)
     assert numpy.abs(sp.stress_ / h_b - 1).max() < tol and _rel(sp.structure_, X_b) < tol
+
+
+def test_single_bin_is_rejected():
+    """N = 1 has no pair: fit() refuses it up front (ValueError), both dtypes."""
+    for dtype in ("float64", "float32"):
+        s = bb.StructureSolver(n_iter=3, lr=0.1, dtype=dtype, kind="wish")
+        with pytest.raises(ValueError, match="at least 2 bins"):
+            s.fit(numpy.zeros((1, 1)), init=numpy.array([[1.0, 2.0, 3.0]]))
