@@ -216,3 +216,39 @@ def test_rccl_single_rank_device_path():
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True,
                        timeout=600, env=env)
     assert "NCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_peer_exchange_call_sequence_errors():
+    """The peer entry points refuse to be used out of order or with handles that do
+    not belong to this job (status codes + bb_last_error, no crash)."""
+    import ctypes
+    from blueberry_amd import _lib
+    from blueberry_amd.solver import HipEngine
+    from tests import _oracle
+    lib = _lib.load()
+    n = 300
+    xs = _oracle.random_walk(n)
+    a = HipEngine(n, "float32", rank=0, world=2)
+    b = HipEngine(n, "float32", rank=1, world=2)
+    other = HipEngine(n + 600, "float32", rank=1, world=2)          # another problem size
+    a.set_wish_from_coords(xs)
+    a.set_coords(xs)
+    buf = lambda: ctypes.create_string_buffer(_lib.BB_PEER_HANDLE_BYTES)
+    ha, hb, ho = buf(), buf(), buf()
+    st = ctypes.c_int()
+    assert lib.bb_solver_iterate_peer(a._h, 1, 0.1) == _lib.BB_ERR_STATE      # not connected
+    assert lib.bb_solver_peer_status(a._h, st) == _lib.BB_ERR_STATE
+    assert lib.bb_solver_peer_connect(a._h, ha) == _lib.BB_ERR_STATE          # export first
+    assert lib.bb_solver_peer_export(a._h, ha) == _lib.BB_OK
+    assert lib.bb_solver_peer_export(a._h, ha) == _lib.BB_ERR_STATE           # once only
+    assert lib.bb_solver_peer_export(b._h, hb) == _lib.BB_OK
+    assert lib.bb_solver_peer_export(other._h, ho) == _lib.BB_OK
+    assert lib.bb_solver_peer_connect(a._h, hb.raw + ha.raw) == _lib.BB_ERR_INVALID   # rank order
+    assert b"does not match" in lib.bb_last_error()
+    assert lib.bb_solver_peer_connect(a._h, ha.raw + ho.raw) == _lib.BB_ERR_INVALID   # other n_bins
+    assert lib.bb_solver_peer_connect(a._h, ha.raw + hb.raw) == _lib.BB_OK
+    assert lib.bb_solver_peer_connect(a._h, ha.raw + hb.raw) == _lib.BB_ERR_STATE     # once only
+    assert lib.bb_solver_peer_status(a._h, st) == _lib.BB_OK and st.value == 0
+    assert lib.bb_solver_peer_export(None, ha) == _lib.BB_ERR_INVALID
+    for e in (a, b, other):
+        e.close()
