@@ -367,11 +367,12 @@ __device__ __forceinline__ void pair_step2(f32x2 delta, f32x2 xi, f32x2 yi, f32x
 }
 
 // d[] holds the unit's 8 wave-loads in row order: d[2*r + k] = row r, load k.
-template <bool NT, int OP>
+template <bool NT, int OP, bool DEFER>
 __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&xrow)[12],
                                                  const float4 *__restrict__ next, StripF32 &st,
                                                  double &stress, __amdgpu_buffer_rsrc_t row_rsrc,
-                                                 unsigned row_voff) {
+                                                 unsigned row_voff, int stage_idx) {
+    extern __shared__ __attribute__((aligned(16))) float row_lds[];
     f32x2 s2 = {0.f, 0.f};
     // The 12 row sums of the unit are collected into lanes 48..59 of one register
     // (after the reduction every lane >= 48 holds the wave total) and leave with
@@ -402,6 +403,10 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&x
         keep = (slot >= 3 * r && slot < 3 * r + 3) ? mine : keep;
     }
 #ifndef BB_ABL_NOSTORE
+    // DEFER: both are issued for every unit and exactly one of them lands -- the LDS
+    // slot is a dummy word while the unit is stored directly, the store's lanes are all
+    // out of range (free) while the unit is parked (see the kernel)
+    if constexpr (DEFER) row_lds[stage_idx] = keep;
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(keep), row_rsrc, row_voff, 0, 0);
 #else
     asm volatile("" ::"v"(keep));
@@ -511,11 +516,24 @@ __device__ __forceinline__ void store_strip(const T (&gc)[(Lay<T, W>::LPR)][Trai
 //   rowpart    3*RPU elements per unit, base shifted to the rank's first tile
 //   colpart    3*VW elements per slot
 //   stresspart one double per wave
-template <typename T, bool W, bool NT, int OP>
+//
+// DEFER (fp32 only): the row sums do not leave the wave unit by unit.  Writing 48
+// bytes to a fresh line per 8 KiB read costs 7.5 % of the kernel at N=50k, and not in
+// issue: a store whose lanes are all out of range is free, so is one that keeps
+// hitting the same line, and grouping 16 units into 768-byte bursts changes nothing
+// -- the write-back cache decides when dirty lines go to HBM, and it sends them into
+// a saturated read stream.  The column partials of the same size cost almost nothing
+// because they are written when a wave is done.  So, when a wave's whole chunk of
+// row sums fits in LDS (cap_units * 48 B per wave: N=50k on one GPU, every multi-GPU
+// share), they are parked there and written out as one contiguous burst when the
+// wave has finished reading: -5.8 % kernel time at N=50k.  A longer chunk parks its
+// LAST cap_units units and stores the ones before them directly.
+template <typename T, bool W, bool NT, int OP, bool DEFER>
 __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
     const T *__restrict__ units, const T *__restrict__ X, const int2 *__restrict__ udesc,
     const int2 *__restrict__ wave_range, const int32_t *__restrict__ wave_slot,
-    T *__restrict__ rowpart, T *__restrict__ colpart, double *__restrict__ stresspart) {
+    T *__restrict__ rowpart, T *__restrict__ colpart, double *__restrict__ stresspart,
+    int cap_units) {
     using Vec = typename Traits<T>::Vec;
     constexpr int VPL = Traits<T>::VPL;
     constexpr int VW = Lay<T, W>::VW;
@@ -524,6 +542,10 @@ __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
     const int2 range = wave_range[w];
     const int ua = range.x, ub = range.y;
     double stress = 0.0;
+    // DEFER: this wave's parking space, cap_units * 12 floats + 4 dummy words
+    extern __shared__ __attribute__((aligned(16))) float row_lds[];
+    const int stage0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (cap_units * 12 + 4);
+    const int park_from = (ub - ua) > cap_units ? (ub - ua) - cap_units : 0;
 
     if (ua < ub) {
         int slot = wave_slot[w];
@@ -600,22 +622,31 @@ __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
             const XRow xrn = xrow_load(dn.x);
             const int2 dnn = udesc[un + 1 < ub ? un + 1 : un];
             unsigned row_voff;
-            if constexpr (sizeof(T) == 4)   // fp32: lanes 48..59 store one of the 12 sums each
-                row_voff = (lane >= 48 && lane < 60)
-                               ? (unsigned)(u - ua) * kRowBytes + (unsigned)(lane - 48) * 4u
-                               : kDropOffset;
-            else                            // fp64: lane 63 stores each row's three sums
+            int stage_slot = 0;
+            if constexpr (sizeof(T) == 4) {
+                // fp32: lanes 48..59 hold one of the unit's 12 sums each.  Units before
+                // park_from are stored directly; the later ones are parked in LDS slot
+                // (k - park_from) and their store is dropped (every lane out of range).
+                const int k = u - ua;
+                const bool parked = DEFER && k >= park_from;
+                const bool mine = lane >= 48 && lane < 60;
+                row_voff = (mine && !parked) ? (unsigned)k * kRowBytes + (unsigned)(lane - 48) * 4u
+                                             : kDropOffset;
+                stage_slot = stage0 + ((mine && parked) ? (k - park_from) * 12 + (lane - 48)
+                                                        : cap_units * 12 + (lane & 3));
+            } else {                        // fp64: lane 63 stores each row's three sums
                 row_voff = lane == 63 ? (unsigned)(u - ua) * kRowBytes : kDropOffset;
+            }
             if constexpr (sizeof(T) == 4) {
 #ifdef BB_ABL_XROW_VECTOR
                 float xs12[12];
 #pragma unroll
                 for (int q = 0; q < 12; ++q) xs12[q] = lane_value(xr.v, q);
-                process_unit_f32<NT, OP>(d, xs12, unit_ptr<T>(units, un, lane), st, stress, row_rsrc,
-                                     row_voff);
+                process_unit_f32<NT, OP, DEFER>(d, xs12, unit_ptr<T>(units, un, lane), st, stress,
+                                                row_rsrc, row_voff, stage_slot);
 #else
-                process_unit_f32<NT, OP>(d, xr.v, unit_ptr<T>(units, un, lane), st, stress, row_rsrc,
-                                     row_voff);
+                process_unit_f32<NT, OP, DEFER>(d, xr.v, unit_ptr<T>(units, un, lane), st, stress,
+                                                row_rsrc, row_voff, stage_slot);
 #endif
             }
             else
@@ -645,6 +676,19 @@ __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
             strip_store(slot);
             ++slot;
             if (u >= ub) break;
+        }
+        if constexpr (DEFER && sizeof(T) == 4) {
+            // the chunk's row sums, (ub - ua) * 12 floats, in one contiguous burst.
+            // Lanes read what other lanes of this wave parked: LDS operations of one
+            // wave execute in program order; the fence is for the compiler.
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int n4 = ((ub - ua) - park_from) * 3;   // float4 count
+            float4 *dst = reinterpret_cast<float4 *>(rowpart + ((int64_t)ua + park_from) * 12);
+            for (int q = lane; q < n4; q += 64) {
+                const float *src = row_lds + stage0 + 4 * q;
+                dst[q] = make_float4(src[0], src[1], src[2], src[3]);
+            }
         }
     }
 
@@ -1059,6 +1103,9 @@ struct bb_solver {
     double *d_f64_tmp = nullptr;  // (n_pad,3) staging for coordinate I/O
     int64_t rowpart_elems = 0, colpart_elems = 0;
     int n_waves = 0, n_slots = 0;
+    int defer_cap_units = 0;       // fp32: units of row sums a wave can park in LDS (0 = none)
+    int64_t defer_lds_bytes = 0;   // dynamic LDS per workgroup for that, 0 = per-unit stores
+    unsigned defer_attr_done = 0;  // kernel variants whose dynamic-LDS ceiling was raised
     int64_t hist_cap = 0, hist_n = 0;
     bool have_wish = false, have_coords = false, grad_pending = false;
 
@@ -1152,9 +1199,26 @@ int build_indices(bb_solver *s) {
     // wave w owns the contiguous chunk [n_local*w/nw, n_local*(w+1)/nw)
     std::vector<int2> wave_range(nw);
     std::vector<int32_t> wave_slot(nw);
-    for (int64_t w = 0; w < nw; ++w)
+    int64_t chunk_max = 0;
+    for (int64_t w = 0; w < nw; ++w) {
         wave_range[w] = make_int2((int)((__int128)s->n_local * w / nw),
                                   (int)((__int128)s->n_local * (w + 1) / nw));
+        chunk_max = std::max<int64_t>(chunk_max, wave_range[w].y - wave_range[w].x);
+    }
+    {
+        // fp32: a wave parks the row sums of (the last cap units of) its chunk in LDS
+        // until it has finished reading (stress_grad_kernel, DEFER); cap is what the
+        // workgroups sharing a CU can hold.  BB_DEFER_ROWS=0 turns it off.
+        const char *e = getenv("BB_DEFER_ROWS");
+        const int64_t wgs_per_cu = std::max<int64_t>(1, (nw / 4 + cus - 1) / cus);
+        const int64_t budget = 156 * 1024 / wgs_per_cu;               // of the CU's 160 KiB
+        const int64_t cap = std::min<int64_t>(chunk_max, (budget / 4 - 16) / 48);
+        const bool on = !(e && atoi(e) == 0);
+        if (s->dtype == BB_F32 && on && cap > 0) {
+            s->defer_cap_units = (int)cap;
+            s->defer_lds_bytes = 4 * (cap * 48 + 16);
+        }
+    }
     // column-partial slots: one per (wave, strip) intersection, in wave order
     std::vector<int32_t> slot_strip;
     for (int64_t w = 0; w < nw; ++w) {
@@ -1270,16 +1334,36 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
                  (s->u_begin - s->t_first * s->L.units_per_tile) * (3 * s->L.rows_per_unit);
     T *colpart = (T *)s->d_part + s->rowpart_elems;
     const dim3 grid(s->n_waves / 4), block(256);
+    // fp32 with the whole chunk of row sums parked in LDS (s->defer_lds_bytes > 0), or the
+    // per-unit store.  The dynamic-LDS ceiling of a kernel is raised once per instantiation.
+#define BB_LAUNCH2(NTV, OPV, DEF, LDS)                                                          \
+    do {                                                                                        \
+        auto kern = stress_grad_kernel<T, W, NTV, OPV, DEF>;                                    \
+        constexpr unsigned bit = 1u << ((NTV ? 2 : 0) + (OPV == kOpMatvec2 ? 1 : 0));          \
+        if ((LDS) > 0 && !(s->defer_attr_done & bit)) {                                        \
+            BB_HIP_CHECK(hipFuncSetAttribute((const void *)kern,                                \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                             (int)(LDS)));                                      \
+            s->defer_attr_done |= bit;                                                          \
+        }                                                                                       \
+        hipLaunchKernelGGL(kern, grid, block, (size_t)(LDS), s->stream, units, X, s->d_udesc,   \
+                           s->d_wave_range, s->d_wave_slot, rowpart, colpart, s->d_stresspart,  \
+                           s->defer_cap_units);                                                 \
+    } while (0)
 #define BB_LAUNCH(NTV, OPV)                                                                     \
-    hipLaunchKernelGGL((stress_grad_kernel<T, W, NTV, OPV>), grid, block, 0, s->stream, units, X, \
-                       s->d_udesc, s->d_wave_range, s->d_wave_slot, rowpart, colpart,          \
-                       s->d_stresspart)
+    do {                                                                                        \
+        if (sizeof(T) == 4 && s->defer_lds_bytes > 0)                                           \
+            BB_LAUNCH2(NTV, OPV, (sizeof(T) == 4), s->defer_lds_bytes);                         \
+        else                                                                                    \
+            BB_LAUNCH2(NTV, OPV, false, 0);                                                     \
+    } while (0)
     if (op == kOpMatvec2) {
         if (s->nontemporal) BB_LAUNCH(true, kOpMatvec2); else BB_LAUNCH(false, kOpMatvec2);
     } else {
         if (s->nontemporal) BB_LAUNCH(true, kOpStress); else BB_LAUNCH(false, kOpStress);
     }
 #undef BB_LAUNCH
+#undef BB_LAUNCH2
     BB_HIP_CHECK(hipGetLastError());
     return BB_OK;
 }
