@@ -1,0 +1,1073 @@
+// bb_solver_kernels.h -- device code of the 3D-structure solver (gfx950 only): the
+// stress + gradient sweep, the deterministic partial reduce (+ update / exchange /
+// peer push), the update kernels, the pack kernels and the read-only sweep used for
+// measurement.  Included by bb_solver.hip (the host side and the C-ABI) and by nothing
+// else: everything here lives in that translation unit's anonymous namespace.
+//
+// Specification: docs/SPEC.md (build-authored; the reference has no solver,
+// SURVEY.md section 0).  Data layout and kernel design: DESIGN.md 3-4.
+//
+// Layout recap (SPEC 3).  The matrix is cut into vw x vw tiles (vw = 512 columns;
+// 128 for small fp64 problems, see Lay<> below), upper-triangular tiles only, ordered
+// column-strip major (J, then I).  A tile is vw/rpu "units"; a unit is rpu matrix rows
+// x vw columns = 8 KiB, row-major (fp32: 4 rows of 2 KiB; fp64: 2 rows of 4 KiB, or 8
+// rows of 1 KiB).
+// One wave reads a matrix row of a unit with LPR 16-B-per-lane loads and lane
+// l always owns the same LPR*VPL columns of the strip.  That makes the column
+// side of the symmetric update register-resident for a whole strip sweep (no
+// cross-lane traffic), and only the row side needs one DPP wave reduction per
+// matrix row -- amortised over 8 pairs per lane in fp32.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "blueberry_hip.h"
+
+namespace {
+
+
+// --------------------------------------------------------------------------
+// type traits
+// --------------------------------------------------------------------------
+template <typename T>
+struct Traits;
+template <>
+struct Traits<float> {
+    using Vec = float4;
+    static constexpr int VPL = 4;  // elements per lane per 16-B load
+    static __device__ __forceinline__ float eps2() { return 1e-30f; }
+};
+template <>
+struct Traits<double> {
+    using Vec = double2;
+    static constexpr int VPL = 2;
+    static __device__ __forceinline__ double eps2() { return 1e-300; }
+};
+
+// Shape of a unit (8 KiB = 8 wave-loads) and of a strip.  LPR 16-byte loads per lane
+// and matrix row, VW = 64 * VPL * LPR columns per strip, RPU = 8 / LPR matrix rows.
+//   fp32          4 rows x 512 columns: 8 pairs per lane and row, packed math
+//   fp64 wide     2 rows x 512 columns: also 8 pairs per lane and row, so the DPP
+//                 reduction, the row-coordinate fetch and the row-sum stores are
+//                 amortised over 4x more pairs than in the narrow shape (+40 % at
+//                 N=20k); 96 VGPRs of column state, so at most 2 waves per SIMD
+//   fp64 narrow   8 rows x 128 columns: 4x smaller column partials and 4x more
+//                 blocks for the reduce -- what small problems want (N=963: 14.5 us
+//                 per iteration against 26 us in the wide shape); bb_common.h picks
+//                 it for n_bins <= kF64WideFrom
+template <typename T, bool W>
+struct Lay;
+template <bool W>
+struct Lay<float, W> {
+    static constexpr int LPR = 2, VW = 512, RPU = 4;
+    static constexpr int MIN_WG = 4;            // __launch_bounds__: <= 128 VGPRs
+    static constexpr bool SCALAR_XROW = true;   // 12 row coordinates through the scalar cache
+};
+template <>
+struct Lay<double, true> {
+    static constexpr int LPR = 4, VW = 512, RPU = 2;
+    static constexpr int MIN_WG = 2;            // <= 256 VGPRs
+    static constexpr bool SCALAR_XROW = true;   // 6 doubles = 12 SGPRs, double-buffered
+};
+template <>
+struct Lay<double, false> {
+    static constexpr int LPR = 1, VW = 128, RPU = 8;
+    static constexpr int MIN_WG = 4;
+    static constexpr bool SCALAR_XROW = false;  // 24 doubles x 2 would not fit the SGPR file:
+                                                // one per-lane load + v_readlane instead
+};
+
+template <int C>
+__device__ __forceinline__ float elem(const float4 &v) {
+    if constexpr (C == 0) return v.x;
+    if constexpr (C == 1) return v.y;
+    if constexpr (C == 2) return v.z;
+    return v.w;
+}
+template <int C>
+__device__ __forceinline__ double elem(const double2 &v) {
+    if constexpr (C == 0) return v.x;
+    return v.y;
+}
+
+// --------------------------------------------------------------------------
+// cross-lane helpers (wave64, DPP; no LDS)
+// --------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_get(double v) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes; the total is valid in lanes 48..63 (we read lane 63).
+// Fixed tree => bitwise deterministic.
+template <typename T>
+__device__ __forceinline__ T wave_sum_hi(T v) {
+    v += dpp_get<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += dpp_get<0x141, 0xF>(v);  // row_half_mirror
+    v += dpp_get<0x140, 0xF>(v);  // row_mirror
+    v += dpp_get<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
+    v += dpp_get<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3
+    return v;
+}
+
+// The same tree for three fp32 values at once, as one asm block.  Interleaving
+// the three chains puts two independent VALU ops between every write of a
+// register and its next DPP read, which is exactly the 2 wait states that
+// hazard needs (the compiler serialises the chains and pads each step with
+// s_nop), and the two row_bcast steps become single v_add_f32_dpp with a
+// partial row_mask (disabled rows keep their value) instead of mov+mov+add.
+// Only the leading s_nop is needed: the inputs were just written by VALU code.
+__device__ __forceinline__ void wave_sum_hi3(float &a, float &b, float &c) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "+v"(a), "+v"(b), "+v"(c));
+}
+__device__ __forceinline__ void wave_sum_hi3(double &a, double &b, double &c) {
+    a = wave_sum_hi(a);
+    b = wave_sum_hi(b);
+    c = wave_sum_hi(c);
+}
+
+// Value of `v` in lane `l` (compile-time l) as a wave-uniform scalar.
+__device__ __forceinline__ float lane_value(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ double lane_value(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// Branch-free "lane 63 only" store of a row's three sums through a raw buffer
+// descriptor: every other lane carries an out-of-range offset and the
+// hardware range check drops its store.  (An `if (lane == 63)` around a plain
+// store splits the unit into basic blocks, and LLVM then sinks all column-side
+// accumulation below the last of them, spilling 32 pairs of forces.)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kDropOffset = 0x80000000u;
+
+__device__ __forceinline__ void store_row3(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, double a,
+                                           double b, double c) {
+    u32x4 v = {(unsigned)__double2loint(a), (unsigned)__double2hiint(a),
+               (unsigned)__double2loint(b), (unsigned)__double2hiint(b)};
+    u32x2 w = {(unsigned)__double2loint(c), (unsigned)__double2hiint(c)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, voff + 16, 0, 0);
+}
+
+// --------------------------------------------------------------------------
+// stress + gradient kernel
+// --------------------------------------------------------------------------
+// What the sweep computes per pair (i, j), template parameter OP:
+//   kOpStress : residual force of SPEC 2.3 -> gradient (row and column side) + stress
+//   kOpMatvec2: y_i += delta_ij^2 * x_j and y_j += delta_ij^2 * x_i for three
+//               right-hand sides held in the coordinate slots: Y = (D o D) X, the
+//               kernel of classical-MDS / spectral initialisation
+enum { kOpStress = 0, kOpMatvec2 = 1 };
+
+// Pair math for one matrix row of a unit: VPL pairs per lane.
+template <typename T, int C, int OP>
+__device__ __forceinline__ void pair_step(const typename Traits<T>::Vec &drow, T xi, T yi, T zi,
+                                          const T (&xj)[Traits<T>::VPL][3],
+                                          T (&gc)[Traits<T>::VPL][3], T &gx, T &gy, T &gz, T &s) {
+    const T delta = elem<C>(drow);
+    if constexpr (OP == kOpMatvec2) {
+        const T a = delta * delta;
+        gx += a * xj[C][0]; gy += a * xj[C][1]; gz += a * xj[C][2];
+        gc[C][0] += a * xi; gc[C][1] += a * yi; gc[C][2] += a * zi;
+        return;
+    }
+    const T dx = xi - xj[C][0], dy = yi - xj[C][1], dz = zi - xj[C][2];
+    const T d2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, Traits<T>::eps2())));  // SPEC 2.2
+    T rinv, dist;
+    if constexpr (sizeof(T) == 4) {
+        rinv = __builtin_amdgcn_rsqf(d2);
+        dist = d2 * rinv;
+    } else {
+#ifdef BB_ABL_F64_LIBM        // timing experiment: library sqrt + IEEE divide (~55 fp64 ops)
+        dist = sqrt(d2);
+        rinv = 1.0 / dist;
+#else
+        // v_rsq_f64 seed, two Newton steps on 1/sqrt, one on sqrt: ~12 fp64 ops,
+        // both results within 1-2 ulp (the parity tolerance is 1e-12)
+        T r = __builtin_amdgcn_rsq(d2);
+        const T h = T(0.5) * d2;
+        r = r * fma(-h * r, r, T(1.5));
+        r = r * fma(-h * r, r, T(1.5));
+        dist = d2 * r;
+        dist = fma(T(0.5) * r, fma(-dist, dist, d2), dist);
+        rinv = r;
+#endif
+    }
+    const T res = delta > T(0) ? dist - delta : T(0);
+    s = fma(res, res, s);
+    const T coef = res * rinv;  // (d - delta) / d ; the factor 2 is applied in the reduce
+    const T fx = coef * dx, fy = coef * dy, fz = coef * dz;
+    gx += fx; gy += fy; gz += fz;
+    gc[C][0] -= fx; gc[C][1] -= fy; gc[C][2] -= fz;
+}
+
+// Matrix rows are read exactly once per launch: NT = true marks the loads
+// non-temporal so the stream does not evict X and the partials from L2 / MALL.
+typedef float f32x4_raw __attribute__((ext_vector_type(4)));
+typedef double f64x2_raw __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ float4 stream_load(const float4 *p) {
+    if constexpr (NT) {
+        const f32x4_raw v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_raw *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ double2 stream_load(const double2 *p) {
+    if constexpr (NT) {
+        const f64x2_raw v = __builtin_nontemporal_load(reinterpret_cast<const f64x2_raw *>(p));
+        return make_double2(v.x, v.y);
+    } else {
+        return *p;
+    }
+}
+
+// One unit, generic (fp64) form: RPU matrix rows of LPR wave-loads each.  Load k of
+// row r of the CURRENT unit is consumed from d[r*LPR + k], which is then refilled at
+// once with the same load of the NEXT unit, so 8 KiB per wave stay in flight with a
+// single register window.  xrow.get(q): the unit's q-th row coordinate, wave-uniform.
+template <typename T, bool W, bool NT, int OP, typename XR>
+__device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[8], const XR &xrow,
+                                             const typename Traits<T>::Vec *__restrict__ next,
+                                             const T (&xj)[(Lay<T, W>::LPR)][Traits<T>::VPL][3],
+                                             T (&gc)[(Lay<T, W>::LPR)][Traits<T>::VPL][3],
+                                             double &stress, __amdgpu_buffer_rsrc_t row_rsrc,
+                                             unsigned row_voff) {
+    constexpr int VPL = Traits<T>::VPL, LPR = Lay<T, W>::LPR;
+    static_assert(Lay<T, W>::RPU * LPR == 8, "a unit is 8 wave-loads");
+    T s = T(0);
+#pragma unroll
+    for (int r = 0; r < Lay<T, W>::RPU; ++r) {
+        const T xi = xrow.get(3 * r), yi = xrow.get(3 * r + 1), zi = xrow.get(3 * r + 2);
+        T gx = T(0), gy = T(0), gz = T(0);
+#pragma unroll
+        for (int k = 0; k < LPR; ++k) {
+            pair_step<T, 0, OP>(d[r * LPR + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
+            pair_step<T, 1, OP>(d[r * LPR + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
+            if constexpr (VPL == 4) {
+                pair_step<T, 2, OP>(d[r * LPR + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
+                pair_step<T, 3, OP>(d[r * LPR + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
+            }
+            d[r * LPR + k] = stream_load<NT>(next + (r * LPR + k) * 64);
+        }
+        wave_sum_hi3(gx, gy, gz);
+        // one 3-element store per matrix row, from the lane holding the sums
+        store_row3(row_rsrc, row_voff + r * 3 * (unsigned)sizeof(T), gx, gy, gz);
+        // keep the rows in program order: otherwise the scheduler interleaves the
+        // rows for ILP and spills
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    stress += (double)s;
+}
+
+// ---- fp32: the same unit with explicit 2-wide packed math (v_pk_*_f32) -------
+// A lane owns 8 columns of the 512-wide strip: load k (k = 0,1) brings columns
+// k*256 + 4*lane .. +3, and within a load the pairs {0,1} and {2,3} share every
+// instruction that has a packed form.  Column-side state is [load][half]
+// [component] so that the two pairs of a half sit in adjacent registers.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct StripF32 {
+    f32x2 x[2][2][3];  // coordinates of this lane's columns
+    f32x2 g[2][2][3];  // column-side gradient accumulators, same shape
+};
+
+// w = 1 where delta > 0, else 0, for both halves in ONE instruction:
+// clamp(delta * 2^100) saturates any delta >= 2^-100 to 1 and leaves 0 at 0
+// (delta is never negative or NaN: the pack kernels store 0 for "no
+// constraint" and flush anything below 1e-30).  Replaces 2 v_cmp + 2 v_cndmask.
+__device__ __forceinline__ f32x2 weight01(f32x2 delta) {
+    f32x2 w;
+    const f32x2 big = {0x1p100f, 0x1p100f};
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(w) : "v"(delta), "v"(big));
+    return w;
+}
+
+template <int K, int H, bool FIRST, int OP>
+__device__ __forceinline__ void pair_step2(f32x2 delta, f32x2 xi, f32x2 yi, f32x2 zi, StripF32 &st,
+                                           f32x2 &rx, f32x2 &ry, f32x2 &rz, f32x2 &s2) {
+    if constexpr (OP == kOpMatvec2) {
+        const f32x2 a = delta * delta;
+        if constexpr (FIRST) {
+            rx = a * st.x[K][H][0]; ry = a * st.x[K][H][1]; rz = a * st.x[K][H][2];
+        } else {
+            rx += a * st.x[K][H][0]; ry += a * st.x[K][H][1]; rz += a * st.x[K][H][2];
+        }
+        st.g[K][H][0] += a * xi;
+        st.g[K][H][1] += a * yi;
+        st.g[K][H][2] += a * zi;
+        return;
+    }
+    const f32x2 eps2 = {1e-30f, 1e-30f};
+    const f32x2 dx = xi - st.x[K][H][0], dy = yi - st.x[K][H][1], dz = zi - st.x[K][H][2];
+    const f32x2 d2 = dx * dx + (dy * dy + (dz * dz + eps2));  // SPEC 2.2: |d|^2 + eps^2
+    f32x2 rinv;
+#ifdef BB_ABL_NORSQ  // timing experiment: wrong results
+    rinv = d2 * eps2;
+#else
+    rinv.x = __builtin_amdgcn_rsqf(d2.x);
+    rinv.y = __builtin_amdgcn_rsqf(d2.y);
+#endif
+#ifdef BB_ABL_NOMASK
+    const f32x2 res = (d2 * rinv - delta);
+#else
+    const f32x2 res = (d2 * rinv - delta) * weight01(delta);  // (dist - delta) or 0
+#endif
+    s2 += res * res;
+    const f32x2 coef = res * rinv;
+    if constexpr (FIRST) {
+        rx = coef * dx; ry = coef * dy; rz = coef * dz;
+    } else {
+        rx += coef * dx; ry += coef * dy; rz += coef * dz;
+    }
+#ifndef BB_ABL_NOCOL
+    st.g[K][H][0] -= coef * dx;
+    st.g[K][H][1] -= coef * dy;
+    st.g[K][H][2] -= coef * dz;
+#endif
+}
+
+// d[] holds the unit's 8 wave-loads in row order: d[2*r + k] = row r, load k.
+template <bool NT, int OP, bool DEFER>
+__device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&xrow)[12],
+                                                 const float4 *__restrict__ next, StripF32 &st,
+                                                 double &stress, __amdgpu_buffer_rsrc_t row_rsrc,
+                                                 unsigned row_voff, int stage_idx) {
+    extern __shared__ __attribute__((aligned(16))) float row_lds[];
+    f32x2 s2 = {0.f, 0.f};
+    // The 12 row sums of the unit are collected into lanes 48..59 of one register
+    // (after the reduction every lane >= 48 holds the wave total) and leave with
+    // ONE 48-byte store per unit: a 12-byte store per row costs as much VMEM issue
+    // as a 1-KiB load and measured 5.6 % of the kernel.
+    const int slot = (int)(threadIdx.x & 63) - 48;  // value index this lane keeps, if 0..11
+    const int comp = slot - 3 * (slot / 3);     // 0,1,2 = x,y,z
+    float keep = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float xs = xrow[3 * r], ys = xrow[3 * r + 1], zs = xrow[3 * r + 2];
+        const f32x2 xi = {xs, xs}, yi = {ys, ys}, zi = {zs, zs};
+        f32x2 rx, ry, rz, qx, qy, qz;  // row-side sums of load 0 / load 1
+        pair_step2<0, 0, true, OP>(f32x2{d[2 * r].x, d[2 * r].y}, xi, yi, zi, st, rx, ry, rz, s2);
+        pair_step2<0, 1, false, OP>(f32x2{d[2 * r].z, d[2 * r].w}, xi, yi, zi, st, rx, ry, rz, s2);
+        d[2 * r] = stream_load<NT>(next + (2 * r) * 64);
+        // (no sched_barrier here: letting the scheduler mix the rows of a unit measured
+        // 1 % faster at N=50k and 6 % faster at 1/8 size; it stays within 125 VGPRs)
+        pair_step2<1, 0, true, OP>(f32x2{d[2 * r + 1].x, d[2 * r + 1].y}, xi, yi, zi, st, qx, qy, qz, s2);
+        pair_step2<1, 1, false, OP>(f32x2{d[2 * r + 1].z, d[2 * r + 1].w}, xi, yi, zi, st, qx, qy, qz, s2);
+        d[2 * r + 1] = stream_load<NT>(next + (2 * r + 1) * 64);
+        rx += qx; ry += qy; rz += qz;
+        float gx = rx.x + rx.y, gy = ry.x + ry.y, gz = rz.x + rz.y;
+#ifndef BB_ABL_NODPP
+        wave_sum_hi3(gx, gy, gz);
+#endif
+        const float mine = comp == 0 ? gx : (comp == 1 ? gy : gz);
+        keep = (slot >= 3 * r && slot < 3 * r + 3) ? mine : keep;
+    }
+#ifndef BB_ABL_NOSTORE
+    // DEFER: both are issued for every unit and exactly one of them lands -- the LDS
+    // slot is a dummy word while the unit is stored directly, the store's lanes are all
+    // out of range (free) while the unit is parked (see the kernel)
+    if constexpr (DEFER) row_lds[stage_idx] = keep;
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(keep), row_rsrc, row_voff, 0, 0);
+#else
+    asm volatile("" ::"v"(keep));
+#endif
+    stress += (double)(s2.x + s2.y);
+}
+
+__device__ __forceinline__ void load_strip_f32(StripF32 &st, const float *__restrict__ X, int j0,
+                                               int lane) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float4 *p = reinterpret_cast<const float4 *>(
+            X + ((int64_t)j0 + k * 256 + (int64_t)lane * 4) * 3);
+        const float4 a = p[0], b = p[1], c = p[2];  // x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3
+        st.x[k][0][0] = f32x2{a.x, a.w}; st.x[k][0][1] = f32x2{a.y, b.x};
+        st.x[k][0][2] = f32x2{a.z, b.y};
+        st.x[k][1][0] = f32x2{b.z, c.y}; st.x[k][1][1] = f32x2{b.w, c.z};
+        st.x[k][1][2] = f32x2{c.x, c.w};
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) st.g[k][h][c3] = f32x2{0.f, 0.f};
+    }
+}
+
+__device__ __forceinline__ void store_strip_f32(const StripF32 &st, float *__restrict__ slot,
+                                                int lane) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float4 *p = reinterpret_cast<float4 *>(slot + (k * 256 + (int64_t)lane * 4) * 3);
+        const auto &g = st.g[k];
+        p[0] = make_float4(g[0][0].x, g[0][1].x, g[0][2].x, g[0][0].y);
+        p[1] = make_float4(g[0][1].y, g[0][2].y, g[1][0].x, g[1][1].x);
+        p[2] = make_float4(g[1][2].x, g[1][0].y, g[1][1].y, g[1][2].y);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ const typename Traits<T>::Vec *unit_ptr(const T *__restrict__ units,
+                                                                   int64_t ul, int lane) {
+    using Vec = typename Traits<T>::Vec;
+    return reinterpret_cast<const Vec *>(units) + ul * 512 + lane;  // 8 KiB = 512 x 16 B
+}
+
+// coordinates of a unit's rows: 3*RPU consecutive elements, one per lane
+template <typename T, bool W>
+__device__ __forceinline__ T load_xrow(const T *__restrict__ X, int i0, int lane) {
+    return X[(int64_t)i0 * 3 + (lane < 3 * Lay<T, W>::RPU ? lane : 0)];
+}
+
+// Generic (fp64) column-strip state: load k of a row brings columns
+// k*64*VPL + lane*VPL .. +VPL-1, so lane l owns 3*VPL consecutive coordinates per k.
+template <typename T, bool W>
+__device__ __forceinline__ void load_strip(T (&xj)[(Lay<T, W>::LPR)][Traits<T>::VPL][3],
+                                           const T *__restrict__ X, int j0, int lane) {
+    using Vec = typename Traits<T>::Vec;
+    constexpr int VPL = Traits<T>::VPL;
+#pragma unroll
+    for (int k = 0; k < Lay<T, W>::LPR; ++k) {
+        const Vec *p = reinterpret_cast<const Vec *>(
+            X + ((int64_t)j0 + k * 64 * VPL + (int64_t)lane * VPL) * 3);
+        Vec a = p[0], b = p[1], c = p[2];
+        if constexpr (VPL == 4) {
+            xj[k][0][0] = a.x; xj[k][0][1] = a.y; xj[k][0][2] = a.z;
+            xj[k][1][0] = a.w; xj[k][1][1] = b.x; xj[k][1][2] = b.y;
+            xj[k][2][0] = b.z; xj[k][2][1] = b.w; xj[k][2][2] = c.x;
+            xj[k][3][0] = c.y; xj[k][3][1] = c.z; xj[k][3][2] = c.w;
+        } else {
+            xj[k][0][0] = a.x; xj[k][0][1] = a.y; xj[k][0][2] = b.x;
+            xj[k][1][0] = b.y; xj[k][1][1] = c.x; xj[k][1][2] = c.y;
+        }
+    }
+}
+
+template <typename T, bool W>
+__device__ __forceinline__ void store_strip(const T (&gc)[(Lay<T, W>::LPR)][Traits<T>::VPL][3],
+                                            T *__restrict__ slot, int lane) {
+    using Vec = typename Traits<T>::Vec;
+    constexpr int VPL = Traits<T>::VPL;
+#pragma unroll
+    for (int k = 0; k < Lay<T, W>::LPR; ++k) {
+        Vec *p = reinterpret_cast<Vec *>(slot + ((int64_t)k * 64 * VPL + (int64_t)lane * VPL) * 3);
+        const auto &g = gc[k];
+        if constexpr (VPL == 4) {
+            p[0] = make_float4(g[0][0], g[0][1], g[0][2], g[1][0]);
+            p[1] = make_float4(g[1][1], g[1][2], g[2][0], g[2][1]);
+            p[2] = make_float4(g[2][2], g[3][0], g[3][1], g[3][2]);
+        } else {
+            p[0] = make_double2(g[0][0], g[0][1]);
+            p[1] = make_double2(g[0][2], g[1][0]);
+            p[2] = make_double2(g[1][1], g[1][2]);
+        }
+    }
+}
+
+// One wave = one contiguous chunk of units; 4 independent waves per workgroup.
+// No LDS, no barriers, no atomics: results are bitwise reproducible.
+//
+// Arguments are separate __restrict__ pointers (not a struct) so that the
+// read-only index arrays are provably unclobbered and load through the scalar
+// cache.  Unit indices are 32-bit (a rank holds < 2^31 units = 16 TiB).
+//   units      this rank's units, 8 KiB (RPU rows x VW columns) each
+//   X          (n_pad, 3) coordinates
+//   udesc      per local unit {i0, j0}
+//   wave_range per wave {first, end} local unit indices
+//   wave_slot  first column-partial slot of each wave
+//   rowpart    3*RPU elements per unit, base shifted to the rank's first tile
+//   colpart    3*VW elements per slot
+//   stresspart one double per wave
+//
+// DEFER (fp32 only): the row sums do not leave the wave unit by unit.  Writing 48
+// bytes to a fresh line per 8 KiB read costs 7.5 % of the kernel at N=50k, and not in
+// issue: a store whose lanes are all out of range is free, so is one that keeps
+// hitting the same line, and grouping 16 units into 768-byte bursts changes nothing
+// -- the write-back cache decides when dirty lines go to HBM, and it sends them into
+// a saturated read stream.  The column partials of the same size cost almost nothing
+// because they are written when a wave is done.  So, when a wave's whole chunk of
+// row sums fits in LDS (cap_units * 48 B per wave: N=50k on one GPU, every multi-GPU
+// share), they are parked there and written out as one contiguous burst when the
+// wave has finished reading: -5.8 % kernel time at N=50k.  A longer chunk parks its
+// LAST cap_units units and stores the ones before them directly.
+template <typename T, bool W, bool NT, int OP, bool DEFER>
+__global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
+    const T *__restrict__ units, const T *__restrict__ X, const int2 *__restrict__ udesc,
+    const int2 *__restrict__ wave_range, const int32_t *__restrict__ wave_slot,
+    T *__restrict__ rowpart, T *__restrict__ colpart, double *__restrict__ stresspart,
+    int cap_units) {
+    using Vec = typename Traits<T>::Vec;
+    constexpr int VPL = Traits<T>::VPL;
+    constexpr int VW = Lay<T, W>::VW;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int2 range = wave_range[w];
+    const int ua = range.x, ub = range.y;
+    double stress = 0.0;
+    // DEFER: this wave's parking space, cap_units * 12 floats + 4 dummy words
+    extern __shared__ __attribute__((aligned(16))) float row_lds[];
+    const int stage0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (cap_units * 12 + 4);
+    const int park_from = (ub - ua) > cap_units ? (ub - ua) - cap_units : 0;
+
+    if (ua < ub) {
+        int slot = wave_slot[w];
+        Vec d[8];  // the unit's 8 wave-loads (8 KiB), in memory order
+        // column-strip state: coordinates + gradient accumulators of this lane's columns
+        struct Generic { T xj[(Lay<T, W>::LPR)][VPL][3], gc[(Lay<T, W>::LPR)][VPL][3]; };
+        using Strip = typename std::conditional<sizeof(T) == 4, StripF32, Generic>::type;
+        Strip st;
+        auto strip_load = [&](int j0) __attribute__((always_inline)) {
+            if constexpr (sizeof(T) == 4) {
+                load_strip_f32(st, X, j0, lane);
+            } else {
+                load_strip<T, W>(st.xj, X, j0, lane);
+#pragma unroll
+                for (int k = 0; k < Lay<T, W>::LPR; ++k)
+#pragma unroll
+                    for (int c = 0; c < VPL; ++c)
+                        st.gc[k][c][0] = st.gc[k][c][1] = st.gc[k][c][2] = T(0);
+            }
+        };
+        auto strip_store = [&](int sl) __attribute__((always_inline)) {
+            if constexpr (sizeof(T) == 4)
+                store_strip_f32(st, colpart + (int64_t)sl * (3 * VW), lane);
+            else
+                store_strip<T, W>(st.gc, colpart + (int64_t)sl * (3 * VW), lane);
+        };
+
+        int2 dc = udesc[ua];                                   // current unit
+        int2 dn = udesc[ua + 1 < ub ? ua + 1 : ua];            // next unit
+        // Prologue: the x rows of the first unit, then its 8 matrix rows.
+        // Row coordinates of a unit, one unit ahead.  XRowS: 3*RPU wave-uniform scalars
+        // fetched through the scalar cache (X is read-only in this kernel) -- no VMEM
+        // slot, no v_readlane (12 floats or 6 doubles: 12 SGPRs, double-buffered).
+        // XRowV (fp64 narrow: 24 doubles): one per-lane load, v_readlane per use.
+        struct XRowS {
+            T v[3 * Lay<T, W>::RPU];
+            __device__ __forceinline__ T get(int q) const { return v[q]; }
+        };
+        struct XRowV {
+            T v;
+            __device__ __forceinline__ T get(int q) const { return lane_value(v, q); }
+        };
+#ifdef BB_ABL_XROW_VECTOR
+        using XRow = XRowV;
+#else
+        using XRow = typename std::conditional<Lay<T, W>::SCALAR_XROW, XRowS, XRowV>::type;
+#endif
+        auto xrow_load = [&](int i0) __attribute__((always_inline)) {
+            XRow x;
+            if constexpr (std::is_same<XRow, XRowS>::value) {
+                const T *px = X + (int64_t)i0 * 3;
+#pragma unroll
+                for (int q = 0; q < 3 * Lay<T, W>::RPU; ++q) x.v[q] = px[q];
+            } else {
+                x.v = load_xrow<T, W>(X, i0, lane);
+            }
+            return x;
+        };
+        XRow xr = xrow_load(dc.x);
+        {
+            const Vec *first = unit_ptr<T>(units, ua, lane);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) d[r] = stream_load<NT>(first + r * 64);
+        }
+        // this wave's row partials: 3*RPU elements per unit of its group's chunk
+        constexpr unsigned kRowBytes = 3 * Lay<T, W>::RPU * sizeof(T);
+        const __amdgpu_buffer_rsrc_t row_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            rowpart + (int64_t)ua * (3 * Lay<T, W>::RPU), 0, (int)((unsigned)(ub - ua) * kRowBytes),
+            0x00020000);
+
+        auto unit_step = [&](int u) __attribute__((always_inline)) {
+            // the wave's last unit "prefetches" itself: harmless, stays in bounds
+            const int un = u + 1 < ub ? u + 1 : u;
+            const XRow xrn = xrow_load(dn.x);
+            const int2 dnn = udesc[un + 1 < ub ? un + 1 : un];
+            unsigned row_voff;
+            int stage_slot = 0;
+            if constexpr (sizeof(T) == 4) {
+                // fp32: lanes 48..59 hold one of the unit's 12 sums each.  Units before
+                // park_from are stored directly; the later ones are parked in LDS slot
+                // (k - park_from) and their store is dropped (every lane out of range).
+                const int k = u - ua;
+                const bool parked = DEFER && k >= park_from;
+                const bool mine = lane >= 48 && lane < 60;
+                row_voff = (mine && !parked) ? (unsigned)k * kRowBytes + (unsigned)(lane - 48) * 4u
+                                             : kDropOffset;
+                stage_slot = stage0 + ((mine && parked) ? (k - park_from) * 12 + (lane - 48)
+                                                        : cap_units * 12 + (lane & 3));
+            } else {                        // fp64: lane 63 stores each row's three sums
+                row_voff = lane == 63 ? (unsigned)(u - ua) * kRowBytes : kDropOffset;
+            }
+            if constexpr (sizeof(T) == 4) {
+#ifdef BB_ABL_XROW_VECTOR
+                float xs12[12];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) xs12[q] = lane_value(xr.v, q);
+                process_unit_f32<NT, OP, DEFER>(d, xs12, unit_ptr<T>(units, un, lane), st, stress,
+                                                row_rsrc, row_voff, stage_slot);
+#else
+                process_unit_f32<NT, OP, DEFER>(d, xr.v, unit_ptr<T>(units, un, lane), st, stress,
+                                                row_rsrc, row_voff, stage_slot);
+#endif
+            }
+            else
+                process_unit<T, W, NT, OP>(d, xr, unit_ptr<T>(units, un, lane), st.xj, st.gc, stress,
+                                       row_rsrc, row_voff);
+            xr = xrn;
+            dc = dn;
+            dn = dnn;
+        };
+        // Outer loop: one trip per column strip the wave's sweep crosses (rare).
+        // Inner loop: the units of that strip, with NO branch in the body.  Its
+        // first unit is peeled, so the inner loop is only ever entered from a
+        // state with the loop body's own pattern of outstanding loads and
+        // stores: hipcc's s_waitcnt counts are static and are merged over every
+        // entry of a loop header, and a prologue- or strip-change-shaped entry
+        // drains most of the 8-row prefetch window on every iteration.
+        int u = ua;
+        for (;;) {
+            const int curj = dc.y;
+            strip_load(curj);
+            unit_step(u);
+            ++u;
+            while (u < ub && dc.y == curj) {
+                unit_step(u);
+                ++u;
+            }
+            strip_store(slot);
+            ++slot;
+            if (u >= ub) break;
+        }
+        if constexpr (DEFER && sizeof(T) == 4) {
+            // the chunk's row sums, (ub - ua) * 12 floats, in one contiguous burst.
+            // Lanes read what other lanes of this wave parked: LDS operations of one
+            // wave execute in program order; the fence is for the compiler.
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int n4 = ((ub - ua) - park_from) * 3;   // float4 count
+            float4 *dst = reinterpret_cast<float4 *>(rowpart + ((int64_t)ua + park_from) * 12);
+            for (int q = lane; q < n4; q += 64) {
+                const float *src = row_lds + stage0 + 4 * q;
+                dst[q] = make_float4(src[0], src[1], src[2], src[3]);
+            }
+        }
+    }
+
+    // per-wave stress (fixed shuffle tree)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) stress += __shfl_down(stress, off, 64);
+    if (lane == 0) stresspart[w] = stress;
+}
+
+// --------------------------------------------------------------------------
+// reduce (+ update) kernel: one workgroup per vw-bin block
+// --------------------------------------------------------------------------
+constexpr int kReduceSlice = 16;  // chunks per stage-1 slice = chunks loaded per round trip
+
+enum ReduceMode {
+    kReduceApply = 0,      // X -= lr * 2 * sum
+    kReduceExchange = 1,   // exch = 2 * sum (+ stress hi/lo)
+    kReduceStressOnly = 2, // stress only
+    kReducePartial = 3,    // stage 1: raw sum of one slice of a block's chunk list
+    kReducePeer = 4        // 2 * sum (+ stress hi/lo) stored into this rank's slot on every peer
+};
+
+// Peer exchange (bb_solver_peer_*): where this rank's partial goes on each rank
+// (its slot in that rank's receive arena, for one parity) and the flag to raise.
+constexpr int kMaxPeers = 16;
+template <typename T>
+struct PeerTable {
+    T *dst[kMaxPeers];
+    unsigned long long *flag[kMaxPeers];
+};
+
+template <typename T>
+struct ReduceParams {
+    const T *__restrict__ part;              // rowpart | colpart
+    const int64_t *__restrict__ blk_ptr;     // n_blocks + 1
+    const int64_t *__restrict__ blk_chunk;   // element offsets into part
+    const double *__restrict__ stresspart;
+    T *__restrict__ X;                       // apply mode
+    T *__restrict__ V;                       // apply mode: velocity (heavy-ball momentum)
+    T mu;                                    // momentum coefficient, 0 = plain gradient step
+    T scale;                                 // 2 for the gradient (SPEC 2.3), 1 for a matvec
+    T *__restrict__ exch;                    // exchange mode: [3*n_pad | hi | lo]
+    T *__restrict__ part_out;                // partial mode: CH elements per workgroup
+    const PeerTable<T> *__restrict__ peer;   // peer mode: destinations, in device memory
+    unsigned *__restrict__ peer_counter;     // peer mode: workgroups done (last one raises flags)
+    unsigned long long seq;                  // peer mode: value the flags take
+    int n_peers;
+    double *__restrict__ stress_out;         // apply / stress-only: where the stress goes
+    int64_t n_pad;
+    int n_waves;
+    int mode;
+    T lr;
+};
+
+template <typename T, bool W>
+__global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
+    constexpr int CH = 3 * Lay<T, W>::VW;
+    constexpr int NE = (CH + 255) / 256;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) T push_stage[CH];   // peer mode only
+    if (p.mode != kReduceStressOnly) {
+        const int64_t k0 = p.blk_ptr[b], k1 = p.blk_ptr[b + 1];
+        T acc[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) acc[j] = T(0);
+        // Chunks are summed in list order (deterministic).  A whole slice of up to
+        // kReduceSlice chunks is loaded before the first add, so a slice costs one
+        // memory round trip, not one per chunk: this kernel is latency-bound.
+        // (fp64: half as many chunks per round trip, for the same 96 VGPRs of loads)
+        constexpr int kBatch = kReduceSlice * 4 / (int)sizeof(T);
+        for (int64_t k = k0; k < k1; k += kBatch) {
+            T v[kBatch][NE];
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) {
+                const bool on = k + q < k1;
+                const T *src = p.part + p.blk_chunk[on ? k + q : k0];
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int e = tid + 256 * j;
+                    v[q][j] = (on && e < CH) ? src[e] : T(0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q)
+#pragma unroll
+                for (int j = 0; j < NE; ++j) acc[j] += v[q][j];
+        }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int e = tid + 256 * j;
+            if (e < CH) {
+                const int64_t o = (int64_t)b * CH + e;
+                if (p.mode == kReducePartial) {
+                    p.part_out[o] = acc[j];
+                } else {
+                    const T g = p.scale * acc[j];
+                    if (p.mode == kReduceApply) {
+                        // SPEC 2.4: V <- mu V - lr g ; X <- X + V   (mu = 0: X -= lr g)
+                        const T v = p.mu * p.V[o] - p.lr * g;
+                        p.V[o] = v;
+                        p.X[o] += v;
+                    } else if (p.mode == kReducePeer) {
+                        push_stage[e] = g;
+                    } else {
+                        p.exch[o] = g;
+                    }
+                }
+            }
+        }
+        if (p.mode == kReducePeer) {
+            // the block's 3*vw values go out as 16-byte stores, 1 KiB per wave
+            // instruction and peer: what crosses xGMI is long contiguous bursts
+            typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+            constexpr int NV = CH * (int)sizeof(T) / 16;
+            __syncthreads();
+            const vec_t *src = (const vec_t *)push_stage;
+            for (int v = tid; v < NV; v += 256) {
+                const vec_t val = src[v];
+                for (int q = 0; q < p.n_peers; ++q)
+                    ((vec_t *)(p.peer->dst[q] + (int64_t)b * CH))[v] = val;
+            }
+        }
+    }
+    if (p.mode == kReducePartial) return;
+    if (b == 0) {
+        __shared__ double sh[256];
+        double s = 0.0;
+        for (int i = tid; i < p.n_waves; i += 256) s += p.stresspart[i];
+        sh[tid] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) sh[tid] += sh[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double S = sh[0];
+            if (p.mode == kReduceExchange) {
+                const T hi = (T)S;
+                p.exch[3 * p.n_pad] = hi;
+                p.exch[3 * p.n_pad + 1] = (T)(S - (double)hi);
+            } else if (p.mode == kReducePeer) {
+                const T hi = (T)S, lo = (T)(S - (double)hi);
+                for (int q = 0; q < p.n_peers; ++q) {
+                    p.peer->dst[q][3 * p.n_pad] = hi;
+                    p.peer->dst[q][3 * p.n_pad + 1] = lo;
+                }
+            } else {
+                *p.stress_out = S;
+            }
+        }
+    }
+    if (p.mode == kReducePeer) {
+        // Every workgroup makes its stores visible system-wide and checks in; the
+        // last one to do so raises this rank's flag on every peer (release).
+        __shared__ int last;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope
+        __syncthreads();
+        if (tid == 0) last = atomicAdd(p.peer_counter, 1u) == gridDim.x - 1;
+        __syncthreads();
+        if (last) {
+            if (tid == 0) atomicExch(p.peer_counter, 0u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (tid < p.n_peers)
+                __hip_atomic_store(p.peer->flag[tid], p.seq, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+
+// Peer exchange, receiving side: wait until every source rank's flag has reached
+// `seq`, then X <- X + (mu V - lr * sum over ranks, in rank order).  The wait is
+// bounded: past `limit` ticks of the constant-rate clock the status word is set,
+// and every later launch returns at once without touching X ("sticky" failure,
+// reported by bb_solver_peer_status).  `arena` is this parity's first slot.
+template <typename T>
+__global__ __launch_bounds__(256) void peer_apply_kernel(
+    T *__restrict__ X, T *__restrict__ V, const T *arena, const unsigned long long *flags,
+    int world, int64_t slot_elems, int64_t n3, T lr, T mu, double *stress_out,
+    unsigned long long seq, int *status, long long limit) {
+    __shared__ int ok;
+    const int tid = threadIdx.x;
+    if (tid == 0) ok = 1;
+    __syncthreads();
+    if (tid < world) {
+        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            ok = 0;
+        } else {
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(flags + 8 * tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) <
+                   seq) {
+                if (wall_clock64() - t0 > limit) {
+                    atomicExch(status, 1);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+    }
+    __syncthreads();
+    if (!ok) return;
+    // The pollers' acquire + the barrier order every thread's loads after the
+    // peers' stores; the arena is uncached memory, read past L1/L2 (sc0 sc1).
+    const int64_t e = (int64_t)blockIdx.x * 256 + tid;
+    if (e < n3) {
+        // all slots are requested before the first add (one memory round trip per
+        // eight ranks, not one per rank); the sum itself runs in rank order
+        T g = T(0);
+        for (int r0 = 0; r0 < world; r0 += 8) {
+            T v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                v[q] = r0 + q < world
+                           ? __hip_atomic_load(arena + (r0 + q) * slot_elems + e, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_SYSTEM)
+                           : T(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (r0 + q < world) g += v[q];
+        }
+        const T v = mu * V[e] - lr * g;
+        V[e] = v;
+        X[e] += v;
+    }
+    if (e == 0) {
+        double S = 0.0;
+        for (int r = 0; r < world; ++r)
+            S += (double)arena[r * slot_elems + n3] + (double)arena[r * slot_elems + n3 + 1];
+        *stress_out = S;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void apply_kernel(T *__restrict__ X, T *__restrict__ V,
+                                                    const T *__restrict__ exch, int64_t n3, T lr,
+                                                    T mu, double *stress_out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n3) {
+        const T v = mu * V[e] - lr * exch[e];
+        V[e] = v;
+        X[e] += v;
+    }
+    if (e == 0 && stress_out) *stress_out = (double)exch[n3] + (double)exch[n3 + 1];
+}
+
+// --------------------------------------------------------------------------
+// packing kernels
+// --------------------------------------------------------------------------
+// staged fp64 rows (row-major, ld = VW) -> units of one run of tiles.
+template <typename T, bool W>
+__global__ __launch_bounds__(256) void convert_units_kernel(
+    const double *__restrict__ stage, T *__restrict__ units_out, const int2 *__restrict__ udesc,
+    int64_t ul0, int64_t stage_row0 /* global row of stage row 0 */, int64_t n_bins, int kind,
+    double neg_inv_alpha) {
+    constexpr int VW = Lay<T, W>::VW;
+    const int64_t ul = ul0 + blockIdx.x;
+    const int2 dsc = udesc[ul];
+    constexpr int RPU = Lay<T, W>::RPU;
+    T *out = units_out + ul * (RPU * VW);
+    for (int e = threadIdx.x; e < RPU * VW; e += 256) {
+        const int r = e / VW, c = e % VW;
+        const int64_t i = (int64_t)dsc.x + r, j = (int64_t)dsc.y + c;
+        double v = 0.0;
+        if (j > i && j < n_bins) {
+            v = stage[(i - stage_row0) * VW + c];
+            const bool ok = (v > 0.0) && (v <= 1.7976931348623157e308);  // finite, positive
+            if (!ok)
+                v = 0.0;
+            else if (kind == BB_KIND_COUNTS)
+                v = pow(v, neg_inv_alpha);
+        }
+        // fp32: the kernel's 0/1 weight needs delta >= 2^-100; anything that small
+        // is below the distance clamp eps = 1e-15 anyway and is stored as "none"
+        if (sizeof(T) == 4 && v < 1e-30) v = 0.0;
+        out[e] = (T)v;
+    }
+}
+
+// Sparse (i, j, value) entries -> resident units (blocked-sparse input).  The
+// units were zeroed ("no constraint") first.  tilemap[I * n_blocks + J] is the
+// tile's index in the global list or -1.
+template <typename T, bool W>
+__global__ __launch_bounds__(256) void scatter_entries_kernel(
+    const int64_t *__restrict__ rows, const int64_t *__restrict__ cols,
+    const double *__restrict__ vals, int64_t nnz, const int32_t *__restrict__ tilemap,
+    int64_t n_blocks, int64_t n_bins, int64_t u_begin, int64_t u_end, T *__restrict__ units,
+    int kind, double neg_inv_alpha, const double *__restrict__ kr,
+    const double *__restrict__ krexp, int *__restrict__ bad) {
+    constexpr int VW = Lay<T, W>::VW, RPU = Lay<T, W>::RPU, UPT = VW / RPU;
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nnz) return;
+    int64_t i = rows[k], j = cols[k];
+    if (i == j) return;                     // the diagonal carries no pair
+    if (i > j) { const int64_t t = i; i = j; j = t; }
+    if (i < 0 || j >= n_bins) { atomicExch(bad, 1); return; }
+    const int64_t I = i / VW, J = j / VW;
+    const int32_t t = tilemap[I * n_blocks + J];
+    if (t < 0) { atomicExch(bad, 2); return; }   // entry outside the tile list
+    const int64_t ri = i - I * VW;
+    const int64_t u = (int64_t)t * UPT + ri / RPU;
+    if (u < u_begin || u >= u_end) return;  // another rank's unit
+    double v = vals[k];
+    // KR balancing + observed/expected, the element-wise form of the loop at
+    // reference datatypes.pyx:166-169 (same operation order)
+    if (kr != nullptr) v = v / (kr[i] * kr[j] * krexp[j - i]);
+    const bool ok = (v > 0.0) && (v <= 1.7976931348623157e308);
+    if (!ok)
+        v = 0.0;
+    else if (kind == BB_KIND_COUNTS)
+        v = pow(v, neg_inv_alpha);
+    if (sizeof(T) == 4 && v < 1e-30) v = 0.0;
+    units[(u - u_begin) * (RPU * VW) + (ri % RPU) * VW + (j - J * VW)] = (T)v;
+}
+
+// delta_ij = |x*_i - x*_j| generated in place (synthetic inputs).
+template <typename T, bool W>
+__global__ __launch_bounds__(256) void gen_units_kernel(const double *__restrict__ xs,
+                                                        T *__restrict__ units_out,
+                                                        const int2 *__restrict__ udesc,
+                                                        int64_t n_bins) {
+    constexpr int VW = Lay<T, W>::VW;
+    const int64_t ul = blockIdx.x;
+    const int2 dsc = udesc[ul];
+    constexpr int RPU = Lay<T, W>::RPU;
+    T *out = units_out + ul * (RPU * VW);
+    for (int e = threadIdx.x; e < RPU * VW; e += 256) {
+        const int r = e / VW, c = e % VW;
+        const int64_t i = (int64_t)dsc.x + r, j = (int64_t)dsc.y + c;
+        double v = 0.0;
+        if (j > i && j < n_bins) {
+            const double dx = xs[3 * i] - xs[3 * j], dy = xs[3 * i + 1] - xs[3 * j + 1],
+                         dz = xs[3 * i + 2] - xs[3 * j + 2];
+            v = sqrt(dx * dx + dy * dy + dz * dz);
+        }
+        if (sizeof(T) == 4 && v < 1e-30) v = 0.0;
+        out[e] = (T)v;
+    }
+}
+
+// Measurement only: the same waves read the same units with the same rolling
+// 8-row window, but do nothing with the data except fold it into a checksum --
+// the practical HBM read ceiling for this access pattern on this box.
+template <bool NT>
+__global__ __launch_bounds__(256, 4) void stream_read_kernel(const float4 *__restrict__ units,
+                                                             const int2 *__restrict__ wave_range,
+                                                             float *__restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int ua = wave_range[w].x, ub = wave_range[w].y;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ua < ub) {
+        float4 d[8];
+        const float4 *first = units + (int64_t)ua * 512 + lane;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) d[r] = stream_load<NT>(first + r * 64);
+        for (int u = ua; u < ub; ++u) {
+            const int un = u + 1 < ub ? u + 1 : u;
+            const float4 *next = units + (int64_t)un * 512 + lane;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                acc.x += d[r].x; acc.y += d[r].y; acc.z += d[r].z; acc.w += d[r].w;
+                d[r] = stream_load<NT>(next + r * 64);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[w] = acc.x;  // keep the loads alive
+}
+
+template <typename T>
+__global__ void f64_to_T_kernel(const double *__restrict__ in, T *__restrict__ out, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) out[e] = (T)in[e];
+}
+template <typename T>
+__global__ void T_to_f64_kernel(const T *__restrict__ in, double *__restrict__ out, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) out[e] = (double)in[e];
+}
+
+}  // namespace
