@@ -97,15 +97,18 @@ int dev_alloc(T **p, int64_t count) {
         if (_rc != BB_OK) return _rc; \
     } while (0)
 
-// Waves per CU (4 waves = one workgroup).  Measured on MI355X (profiles/
-// r01_sweeps.txt): with the rolling 8-KiB window one wave per SIMD already keeps
-// enough bytes in flight, and fewer, longer chunks mean fewer column-partial
-// slots and less prologue per byte: 4/CU wins below ~400k units per rank
-// (-12 % kernel time at 1/8 of the N=50k matrix), 4 and 8 tie above, 16 is
-// 2 % slower.  BB_WAVES_PER_CU overrides.
+// Waves per CU (4 waves = one workgroup).  Measured on MI355X: with the rolling
+// 8-KiB window one wave per SIMD already keeps enough bytes in flight, and fewer,
+// longer chunks mean fewer column-partial slots and less prologue per byte; two
+// waves per SIMD overlap one wave's VALU work with the other's waits.  With the
+// current kernel (profiles/r01_sweep_wpc.txt): 8/CU is 2-4 % faster from ~150k units
+// per rank (N=24,926) up, 4 and 8 tie at 77k units (1/8 of the N=50k matrix, where
+// 4 means half as many column partials for the reduce), 6 is always worse (a
+// workgroup count that is not a multiple of the CU count), 16 is 2 % slower.
+// BB_WAVES_PER_CU overrides.
 int waves_per_cu(int64_t n_local) {
     const char *e = getenv("BB_WAVES_PER_CU");
-    int v = e ? atoi(e) : (n_local >= 400000 ? 8 : 4);
+    int v = e ? atoi(e) : (n_local >= 100000 ? 8 : 4);
     if (v < 1) v = 1;
     if (v > 32) v = 32;
     return v;
