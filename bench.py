@@ -5,6 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` without a launcher starts its own N ranks -- as child
+processes, before this process has made a single GPU call -- and relays rank 0's
+line and the children's exit code.
+
 A "step" is one solver iteration (stress + gradient over every bin pair, then
 the coordinate update) on the workload BASELINE.json's metric is quoted on:
 a dense synthetic N = 50,000-bin wish-distance matrix, fp32, resident in HBM
@@ -59,7 +63,44 @@ def parse():
                     help="third leg: step = relax / (2 N), an over-relaxed majorisation step")
     ap.add_argument("--relax-momentum", type=float, default=0.4,
                     help="heavy-ball coefficient of the third leg")
+    ap.add_argument("--reps", type=int, default=5,
+                    help="further repetitions of the --steps block after the timed one, for "
+                         "the spread of ms_per_step (0 = none)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """--gpus N with no launcher around us: become the launcher.  The N ranks are
+    child processes of a `torch.distributed.run` started HERE, before this process
+    has touched the GPU (bench.py imports neither torch nor the HIP library up to this
+    point), so nothing that holds a GPU context is ever re-executed.  Rank 0's JSON
+    line is relayed on stdout, everything else goes to stderr, and the exit code is
+    the launcher's."""
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{"metric"'):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line:
+        print(line)
+        sys.stdout.flush()
+    if rc == 0 and not line:
+        sys.stderr.write("bench.py: the ranks exited cleanly but printed no result line\n")
+        rc = 1
+    sys.exit(rc)
 
 
 def random_walk(n, seed=0):
@@ -131,14 +172,17 @@ def cpu_baseline(n, iters):
 
 
 def pmc_traffic(n_bins, dtype, world):
-    """HBM bytes per launch of the dominant kernel from a committed rocprofv3
-    PMC pass on this configuration, or None (profiles/pmc_latest.json)."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    passes on this configuration (profiles/pmc_latest.json: one entry per problem
+    size, written by tools/tools_pmc.sh), or None.  It is replayed from the profile,
+    not measured in this run: counters need their own rocprofv3 passes."""
     p = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         with open(p) as fh:
             d = json.load(fh)
-        if d.get("bins") == n_bins and d.get("dtype") == dtype and d.get("gpus", 1) == world:
-            return d.get("hbm_bytes_per_launch")
+        for e in d.get("entries", [d]):
+            if e.get("bins") == n_bins and e.get("dtype") == dtype and e.get("gpus", 1) == world:
+                return e.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
     return None
@@ -165,9 +209,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "--nproc-per-node %d" % (a.gpus, a.gpus))
+        if world == 1 and a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            self_launch(a)                     # does not return
         a.gpus = world
 
     torch = dist = None
@@ -180,7 +223,12 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        local_rank = local_rank % max(1, torch.cuda.device_count())
+        n_dev = torch.cuda.device_count()      # counting does not initialise the GPU
+        if a.backend == "nccl" and world > max(1, n_dev):
+            # more ranks than GPUs (a rehearsal on a smaller box): RCCL refuses two ranks
+            # on one device, so the sum over ranks goes through gloo and host memory
+            a.backend = "gloo"
+        local_rank = local_rank % max(1, n_dev)
         torch.cuda.set_device(local_rank)
         with stdout_to_stderr():
             if a.backend == "nccl":
@@ -207,7 +255,7 @@ def main():
         # exchange inside the solver's own kernels if it validates against RCCL and
         # is faster, else the library's RCCL communicator (BB_COMM overrides)
         with stdout_to_stderr():
-            select_exchange(eng, lr)
+            select_exchange(eng, lr, trial=True)
 
     def steps(k, step=None):
         # world 1: one C call enqueues k fused iterations.  world > 1: grad ->
@@ -233,11 +281,37 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     tim = eng.timing()
+    dt_mine = dt
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64,
                          device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # what every rank saw: kernel, reduce, whole device-side step, its own wall clock
+    mine = {"rank": rank, "kernel_ms": tim["grad_ms"], "reduce_ms": tim["reduce_ms"],
+            "device_step_ms": tim["step_ms"],
+            "exchange_update_gaps_ms": max(0.0, tim["step_ms"] - tim["grad_ms"] - tim["reduce_ms"])
+            if tim["step_ms"] > 0 else None,
+            "wall_ms_per_step": dt_mine / a.steps * 1e3}
+    per_rank = [mine]
+    if use_dist and world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    # spread: the same K-step block a few more times (the timed one above is `value`)
+    eng.set_timing(False)
+    reps = []
+    for _ in range(max(0, a.reps)):
+        fence()
+        t1 = time.perf_counter()
+        steps(a.steps)
+        fence()
+        r = time.perf_counter() - t1
+        if use_dist:
+            t = torch.tensor([r], dtype=torch.float64,
+                             device="cuda" if a.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            r = float(t.item())
+        reps.append(r / a.steps * 1e3)
 
     hist = eng.stress_history()
     traffic = eng.traffic()
@@ -245,6 +319,7 @@ def main():
                 "rccl": "library-owned RCCL communicator", "torch": "torch.distributed (RCCL)",
                 "host": "gloo, host-staged (rehearsal)", None: "none"}[eng._comm_state]
     comm_trial = eng._comm_trial
+    rccl_world = eng.comm_world() if eng._comm_state == "rccl" else None
 
     # BASELINE metric, second half: wall-clock from a resident matrix and the
     # noisy start X0 to S_k / S_0 <= 1e-3 (the synthetic matrix has a zero-stress
@@ -294,6 +369,9 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
+            # the same K-step block repeated --reps more times after the timed one
+            "ms_per_step_reps": {"n": len(reps), "min": min(reps), "median": sorted(reps)[len(reps) // 2],
+                                 "max": max(reps)} if reps else None,
             "higher_is_better": True,
             "scaling": a.scaling,
             "vs_baseline": None,
@@ -305,7 +383,9 @@ def main():
                        "bins": n, "pairs_per_step": pairs,
                        "parallelism": "unit-range sharding x%d + all-reduce(3*n_pad+2) via %s"
                                       % (world, eng_comm) if world > 1 else "1 gpu",
-                       "exchange": eng._comm_state, "exchange_trial": comm_trial},
+                       "exchange": eng._comm_state, "exchange_trial": comm_trial,
+                       "backend": a.backend if use_dist else None,
+                       "rccl_reported_world": rccl_world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(n, a.dtype, world),
@@ -323,6 +403,10 @@ def main():
                                              if read_ms else None),
                          "frac_of_stream_read": (read_ms / tim["grad_ms"]
                                                  if read_ms and tim["grad_ms"] > 0 else None)},
+            "ranks": per_rank if world > 1 else None,
+            "rank_skew_ms_per_step": (max(r["wall_ms_per_step"] for r in per_rank) -
+                                      min(r["wall_ms_per_step"] for r in per_rank))
+            if world > 1 else None,
             "stress_first_last": [float(hist[0]), float(hist[-1])] if hist.size else None,
             "time_to_stress_1e-3": conv,
             "time_to_stress_1e-3_momentum": conv_mu,

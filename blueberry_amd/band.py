@@ -1,4 +1,6 @@
 """count_band_regions -- host side of K1 (reference: blueberry/blueberry.pyx:77-91)."""
+import os
+
 import numpy
 
 from . import _lib
@@ -15,7 +17,7 @@ def _as_regions(regions_ndarray):
     return r
 
 
-def count_band_regions(regions_ndarray, device=0, distributed=False):
+def count_band_regions(regions_ndarray, device=None, distributed=False):
     """Calculate the number of regions in the band.
 
     Same contract as `blueberry.count_band_regions` (pyx:77-91): the number of
@@ -25,7 +27,12 @@ def count_band_regions(regions_ndarray, device=0, distributed=False):
     distributed=True (inside an initialised torch.distributed job): rows are
     sharded over the ranks and the shares summed with an integer all-reduce;
     every rank returns the full count.
+
+    device: HIP device index.  None = device 0, or, with distributed=True, this
+    rank's own GPU (LOCAL_RANK, as StructureSolver picks it) -- an RCCL job must not
+    put every rank's kernel and all-reduce tensor on cuda:0.
     """
+    device = pick_device(device, distributed)
     r = _as_regions(regions_ndarray)
     lib = _lib.load()
     n = r.shape[0]
@@ -43,6 +50,13 @@ def count_band_regions(regions_ndarray, device=0, distributed=False):
                                       HIGH_FITHIC_CUTOFF, i_begin, i_end, device, out),
                "bb_band_count_rows")
     return int(allreduce_count(int(out.value), device))
+
+
+def pick_device(device, distributed):
+    """An explicit index wins; else LOCAL_RANK in a distributed call, 0 otherwise."""
+    if device is not None:
+        return int(device)
+    return int(os.environ.get("LOCAL_RANK", "0")) if distributed else 0
 
 
 def band_row_share(n, rank, world):

@@ -1,0 +1,46 @@
+// bb_ablate.h -- timing-only ablation switches of the solver kernels.  NEVER defined in
+// the product build (build.sh): each BB_ABL_* macro removes one part of
+// stress_grad_kernel so that tools/tools_abl.sh can price it (the results are wrong by
+// design).  The kernels test the constexpr flags below, so the product source carries
+// no #ifdef and the product object no trace of them.
+#pragma once
+
+namespace abl {
+#define BB_ABL_FLAG(name, macro) constexpr bool name = macro
+#ifdef BB_ABL_NODPP          // no cross-lane reduction of the row sums
+BB_ABL_FLAG(kNoDpp, true);
+#else
+BB_ABL_FLAG(kNoDpp, false);
+#endif
+#ifdef BB_ABL_NORSQ          // a multiply instead of v_rsq_f32
+BB_ABL_FLAG(kNoRsq, true);
+#else
+BB_ABL_FLAG(kNoRsq, false);
+#endif
+#ifdef BB_ABL_NOMASK         // no "no constraint" weight
+BB_ABL_FLAG(kNoMask, true);
+#else
+BB_ABL_FLAG(kNoMask, false);
+#endif
+#ifdef BB_ABL_NOCOL          // no column-side accumulation
+BB_ABL_FLAG(kNoCol, true);
+#else
+BB_ABL_FLAG(kNoCol, false);
+#endif
+#ifdef BB_ABL_NOSTORE        // row sums are not stored
+BB_ABL_FLAG(kNoStore, true);
+#else
+BB_ABL_FLAG(kNoStore, false);
+#endif
+#ifdef BB_ABL_XROW_VECTOR    // row coordinates by per-lane load + v_readlane, not scalar loads
+BB_ABL_FLAG(kXrowVector, true);
+#else
+BB_ABL_FLAG(kXrowVector, false);
+#endif
+#ifdef BB_ABL_F64_LIBM       // fp64: library sqrt + IEEE divide instead of rsq + Newton
+BB_ABL_FLAG(kF64Libm, true);
+#else
+BB_ABL_FLAG(kF64Libm, false);
+#endif
+#undef BB_ABL_FLAG
+}  // namespace abl

@@ -22,13 +22,11 @@ int use_device(int device) {
     if (device < 0 || device >= count)
         return fail(BB_ERR_INVALID, "device index out of range");
     BB_HIP_CHECK(hipSetDevice(device));
-    (void)hipGetLastError();
     return BB_OK;
 }
 
 int enter_device(int device) {
     BB_HIP_CHECK(hipSetDevice(device));
-    (void)hipGetLastError();
     return BB_OK;
 }
 

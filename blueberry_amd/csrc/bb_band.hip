@@ -134,9 +134,8 @@ int bb_band_count_rows(const double *regions, int64_t n, int32_t low, int32_t hi
         if (grid.y > 65535u) {
             e = hipErrorInvalidValue;
         } else {
-            hipLaunchKernelGGL(band_count_kernel, grid, dim3(kIB), 0, st, c->d_r, n, (double)low,
-                               (double)high, i_begin, i_end, c->d_out);
-            e = hipGetLastError();
+            e = bb::launch(band_count_kernel, grid, dim3(kIB), 0, st, c->d_r, n, (double)low,
+                           (double)high, i_begin, i_end, c->d_out);
         }
     }
     if (e == hipSuccess)

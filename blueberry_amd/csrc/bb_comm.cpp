@@ -20,6 +20,8 @@ const Rccl &rccl() {
         table.GetUniqueId = (decltype(table.GetUniqueId))dlsym(h, "ncclGetUniqueId");
         table.CommInitRank = (decltype(table.CommInitRank))dlsym(h, "ncclCommInitRank");
         table.CommDestroy = (decltype(table.CommDestroy))dlsym(h, "ncclCommDestroy");
+        table.CommCount = (decltype(table.CommCount))dlsym(h, "ncclCommCount");
+        table.CommAbort = (decltype(table.CommAbort))dlsym(h, "ncclCommAbort");
         table.AllReduce = (decltype(table.AllReduce))dlsym(h, "ncclAllReduce");
         table.GetErrorString = (decltype(table.GetErrorString))dlsym(h, "ncclGetErrorString");
         table.ok = table.GetUniqueId && table.CommInitRank && table.CommDestroy &&

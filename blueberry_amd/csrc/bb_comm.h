@@ -18,6 +18,8 @@ struct Rccl {
     int (*GetUniqueId)(UniqueId *) = nullptr;
     int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
+    int (*CommCount)(const Comm, int *) = nullptr;
+    int (*CommAbort)(Comm) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;

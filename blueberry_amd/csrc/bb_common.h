@@ -6,6 +6,8 @@
 #include <stdint.h>
 
 #include <string>
+#include <tuple>
+#include <utility>
 
 #include "blueberry_hip.h"
 
@@ -48,11 +50,31 @@ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 // Select the device, failing loudly when there is none.
 int use_device(int device);
-// Entry of every call on an existing solver: select its device and drop whatever
-// error an earlier HIP call of this thread left behind (hipGetLastError is
-// per-thread and sticky, and the thread is shared with the caller's other HIP
-// users -- torch, RCCL), so that a launch check reports our launch only.
+// Entry of every call on an existing handle: select its device.  Nothing else: the
+// thread's sticky "last error" is left alone (see launch() below).
 int enter_device(int device);
+
+// Kernel launch that hands back the launch's OWN status (hipLaunchKernel returns it).
+// The library never reads hipGetLastError(): that word is per-thread, sticky, and shared
+// with every other HIP user of the calling thread (torch, RCCL), so a launch check made
+// through it can report somebody else's old failure -- or, if it is cleared first, hide
+// one.  Every HIP call here is checked by its own return value instead; the few probes
+// that are allowed to fail (an attribute an older runtime lacks, a memory flavour the
+// device does not offer) consume their error on the spot with hipGetLastError().
+template <typename... P, size_t... I>
+inline hipError_t launch_impl(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds,
+                              hipStream_t stream, std::tuple<P...> &vals,
+                              std::index_sequence<I...>) {
+    void *ptrs[sizeof...(P) ? sizeof...(P) : 1] = {(void *)&std::get<I>(vals)...};
+    return hipLaunchKernel((const void *)kernel, grid, block, ptrs, lds, stream);
+}
+template <typename... P, typename... A>
+inline hipError_t launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds,
+                         hipStream_t stream, A &&...args) {
+    static_assert(sizeof...(P) == sizeof...(A), "kernel argument count");
+    std::tuple<P...> vals{static_cast<P>(std::forward<A>(args))...};
+    return launch_impl(kernel, grid, block, lds, stream, vals, std::index_sequence_for<P...>{});
+}
 
 // A device allocation that frees itself (host-staged entry points).
 struct DevBuf {

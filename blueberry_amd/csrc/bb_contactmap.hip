@@ -113,18 +113,17 @@ int bb_contactmap_scatter(const double *triples, int64_t n, int32_t resolution, 
     if (e == hipSuccess) e = hipMemsetAsync(bad.p, 0, sizeof(int), st);
     if (e == hipSuccess && n > 0) {
         const unsigned grid = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(scatter_mark_kernel, dim3(grid), dim3(256), 0, st,
-                           (const double *)tr.p, n, (double)resolution, d, (int *)win.p,
-                           (int *)bad.p);
-        hipLaunchKernelGGL(scatter_store_kernel, dim3(grid), dim3(256), 0, st,
+        e = bb::launch(scatter_mark_kernel, dim3(grid), dim3(256), 0, st, (const double *)tr.p, n,
+                       (double)resolution, d, (int *)win.p, (int *)bad.p);
+        if (e == hipSuccess)
+            e = bb::launch(scatter_store_kernel, dim3(grid), dim3(256), 0, st,
                            (const double *)tr.p, n, (double)resolution, d, (const int *)win.p,
                            (double *)m.p);
-        e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&host_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess)
         e = hipMemcpyAsync(matrix, m.p, (size_t)d * d * sizeof(double), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpy(&host_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost);
     if (st) hipStreamDestroy(st);
     if (e != hipSuccess)
         return bb::fail(BB_ERR_HIP, std::string("bb_contactmap_scatter: ") + hipGetErrorString(e));
@@ -159,10 +158,8 @@ int bb_contactmap_normalize(double *matrix, int64_t n_bins, const double *KRnorm
         e = hipMemcpyAsync(ke.p, KRexpected, (size_t)n_bins * sizeof(double), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         const unsigned nt = (unsigned)((d + kT - 1) / kT);
-        hipLaunchKernelGGL(normalize_kernel, dim3(nt, nt), dim3(kT * 8), 0, st,
-                           (const double *)in.p, (double *)out.p, d, n_bins, (const double *)kr.p,
-                           (const double *)ke.p);
-        e = hipGetLastError();
+        e = bb::launch(normalize_kernel, dim3(nt, nt), dim3(kT * 8), 0, st, (const double *)in.p,
+                       (double *)out.p, d, n_bins, (const double *)kr.p, (const double *)ke.p);
     }
     if (e == hipSuccess)
         e = hipMemcpyAsync(matrix, out.p, (size_t)d * d * sizeof(double), hipMemcpyDeviceToHost, st);

@@ -2,7 +2,7 @@
 //   benjamini_hochberg   blueberry/blueberry.pyx:40-75   (sequential running max)
 //   downsample           blueberry/blueberry.pyx:93-104  (5x5 max-pool, in place)
 // Both are exact (max / min only, plus one multiply and one divide per element
-// in the reference's operation order), pinned by golden vectors.
+// in the reference's operation order, NaN behaviour included), pinned by golden vectors.
 #include "bb_common.h"
 
 namespace {
@@ -10,81 +10,145 @@ namespace {
 constexpr int kScanBlock = 256;
 constexpr int kItems = 4;  // per thread -> 1024 elements per workgroup
 
-// q_i = max_{k<=i} min(p_k * n / (k+1), 1): phase 1 = per-workgroup inclusive max-scan
+// The reference's loop (pyx:66-71) is
+//     q = p[i] * n / (i+1);  q = min(q, 1);  q = max(q, prev);  prev = q
+// and Cython lowers min(q, 1) to `1 < q ? 1 : q` and max(q, prev) to `prev > q ? prev : q`.
+// For ordinary numbers that is a running maximum; a NaN p-value comes out as NaN AND,
+// because `NaN > q` is false, restarts the maximum at the next element (golden cases
+// bh_*_4..7).  So the scan runs over pairs (v, cut): v = the running value since the last
+// NaN, cut = "a NaN lies in this range, nothing from before it gets through".
+struct BhRun {
+    double v;
+    int cut;
+};
+__device__ __forceinline__ double ref_max(double prev, double q) { return prev > q ? prev : q; }
+// `later` follows `earlier` in the sequence
+__device__ __forceinline__ BhRun bh_join(BhRun earlier, BhRun later) {
+    BhRun r;
+    r.v = later.cut ? later.v : ref_max(earlier.v, later.v);
+    r.cut = earlier.cut | later.cut;
+    return r;
+}
+__device__ __forceinline__ BhRun bh_identity() {
+    BhRun r;
+    r.v = -__builtin_huge_val();  // -inf > q is false for every q: lets q through
+    r.cut = 0;
+    return r;
+}
+
+// inclusive scan of one BhRun per thread over the workgroup (Hillis-Steele)
+__device__ __forceinline__ BhRun bh_block_scan(BhRun mine, double *shv, int *shc, int tid) {
+    shv[tid] = mine.v;
+    shc[tid] = mine.cut;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {
+        BhRun o = bh_identity();
+        if (tid >= off) { o.v = shv[tid - off]; o.cut = shc[tid - off]; }
+        __syncthreads();
+        BhRun me;
+        me.v = shv[tid];
+        me.cut = shc[tid];
+        me = bh_join(o, me);
+        shv[tid] = me.v;
+        shc[tid] = me.cut;
+        __syncthreads();
+    }
+    BhRun r;
+    r.v = shv[tid];
+    r.cut = shc[tid];
+    return r;
+}
+
+// phase 1: the scan inside each workgroup's 1024 elements; per workgroup its summary and
+// the index of its first NaN (what came before the workgroup still reaches up to there)
 __global__ __launch_bounds__(kScanBlock) void bh_local_kernel(const double *__restrict__ p,
                                                               int64_t d, double n,
                                                               double *__restrict__ q,
-                                                              double *__restrict__ blockmax) {
-    __shared__ double sh[kScanBlock];
+                                                              double *__restrict__ blockv,
+                                                              int *__restrict__ blockcut,
+                                                              int *__restrict__ firstcut) {
+    __shared__ double shv[kScanBlock];
+    __shared__ int shc[kScanBlock];
+    __shared__ int first;
     const int tid = threadIdx.x;
+    if (tid == 0) first = kScanBlock * kItems;
+    __syncthreads();
     const int64_t base = ((int64_t)blockIdx.x * kScanBlock + tid) * kItems;
-    double v[kItems];
-    double run = 0.0;  // the reference starts from prev_q_value = 0.0
+    BhRun v[kItems];
+    BhRun run = bh_identity();
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
         const int64_t i = base + k;
-        double t = 0.0;
         if (i < d) {
-            t = p[i] * n / (double)(i + 1);
-            t = t < 1.0 ? t : 1.0;
+            double t = p[i] * n / (double)(i + 1);
+            t = 1.0 < t ? 1.0 : t;                   // min(q, 1) as the reference evaluates it
+            BhRun e;
+            e.v = t;
+            e.cut = t != t;
+            run = bh_join(run, e);
+            if (e.cut) atomicMin(&first, tid * kItems + k);
         }
-        run = t > run ? t : run;
         v[k] = run;
     }
-    sh[tid] = run;
-    __syncthreads();
-    for (int off = 1; off < kScanBlock; off <<= 1) {  // Hillis-Steele inclusive max-scan
-        double o = tid >= off ? sh[tid - off] : 0.0;
-        __syncthreads();
-        sh[tid] = o > sh[tid] ? o : sh[tid];
-        __syncthreads();
-    }
-    const double before = tid > 0 ? sh[tid - 1] : 0.0;
+    const BhRun incl = bh_block_scan(run, shv, shc, tid);
+    BhRun before = bh_identity();
+    if (tid > 0) { before.v = shv[tid - 1]; before.cut = shc[tid - 1]; }
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
         const int64_t i = base + k;
-        if (i < d) q[i] = before > v[k] ? before : v[k];
+        if (i < d) q[i] = bh_join(before, v[k]).v;
     }
-    if (tid == kScanBlock - 1) blockmax[blockIdx.x] = sh[tid];
+    if (tid == kScanBlock - 1) {
+        blockv[blockIdx.x] = incl.v;
+        blockcut[blockIdx.x] = incl.cut;
+        firstcut[blockIdx.x] = first;
+    }
 }
 
-// phase 2: exclusive max-scan of the workgroup maxima (one workgroup, sequential over chunks)
-__global__ __launch_bounds__(kScanBlock) void bh_blockscan_kernel(double *__restrict__ blockmax,
+// phase 2: exclusive scan of the workgroup summaries (one workgroup, sequential over
+// chunks), seeded with the reference's prev_q_value = 0.0
+__global__ __launch_bounds__(kScanBlock) void bh_blockscan_kernel(double *__restrict__ blockv,
+                                                                  int *__restrict__ blockcut,
                                                                   int64_t nblocks) {
-    __shared__ double sh[kScanBlock];
-    __shared__ double carry;
+    __shared__ double shv[kScanBlock];
+    __shared__ int shc[kScanBlock];
+    __shared__ double carry_v;
+    __shared__ int carry_c;
     const int tid = threadIdx.x;
-    if (tid == 0) carry = 0.0;
+    if (tid == 0) { carry_v = 0.0; carry_c = 0; }
     __syncthreads();
     for (int64_t c0 = 0; c0 < nblocks; c0 += kScanBlock) {
         const int64_t i = c0 + tid;
-        const double mine = i < nblocks ? blockmax[i] : 0.0;
-        sh[tid] = mine;
+        BhRun mine = bh_identity();
+        if (i < nblocks) { mine.v = blockv[i]; mine.cut = blockcut[i]; }
+        const BhRun incl = bh_block_scan(mine, shv, shc, tid);
+        BhRun c;
+        c.v = carry_v;
+        c.cut = carry_c;
+        BhRun excl = bh_identity();
+        if (tid > 0) { excl.v = shv[tid - 1]; excl.cut = shc[tid - 1]; }
+        if (i < nblocks) blockv[i] = bh_join(c, excl).v;   // what reaches workgroup i from before
         __syncthreads();
-        for (int off = 1; off < kScanBlock; off <<= 1) {
-            double o = tid >= off ? sh[tid - off] : 0.0;
-            __syncthreads();
-            sh[tid] = o > sh[tid] ? o : sh[tid];
-            __syncthreads();
+        if (tid == kScanBlock - 1) {
+            const BhRun nc = bh_join(c, incl);
+            carry_v = nc.v;
+            carry_c = nc.cut;
         }
-        const double c = carry;
-        const double excl = tid > 0 ? sh[tid - 1] : 0.0;
-        if (i < nblocks) blockmax[i] = c > excl ? c : excl;  // max over all earlier workgroups
-        __syncthreads();
-        if (tid == kScanBlock - 1) carry = c > sh[tid] ? c : sh[tid];
         __syncthreads();
     }
 }
 
-// phase 3: fold the prefix of earlier workgroups in
+// phase 3: fold what came before the workgroup into its elements up to its first NaN
 __global__ __launch_bounds__(kScanBlock) void bh_apply_kernel(double *__restrict__ q, int64_t d,
-                                                              const double *__restrict__ prefix) {
+                                                              const double *__restrict__ prefix,
+                                                              const int *__restrict__ firstcut) {
     const double pre = prefix[blockIdx.x];
+    const int first = firstcut[blockIdx.x];
     const int64_t base = ((int64_t)blockIdx.x * kScanBlock + threadIdx.x) * kItems;
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
         const int64_t i = base + k;
-        if (i < d) q[i] = pre > q[i] ? pre : q[i];
+        if (i < d && threadIdx.x * kItems + k < first) q[i] = ref_max(pre, q[i]);
     }
 }
 
@@ -117,24 +181,28 @@ int bb_benjamini_hochberg(const double *p_values, int64_t d, int64_t n, double *
     if (d == 0) return BB_OK;
     const int64_t per_block = (int64_t)kScanBlock * kItems;
     const int64_t nblocks = (d + per_block - 1) / per_block;
-    bb::DevBuf p, q, bm;
+    bb::DevBuf p, q, bm, bc, fc;
     hipStream_t st = nullptr;
     hipError_t e = p.alloc((size_t)d * 8);
     if (e == hipSuccess) e = q.alloc((size_t)d * 8);
     if (e == hipSuccess) e = bm.alloc((size_t)nblocks * 8);
+    if (e == hipSuccess) e = bc.alloc((size_t)nblocks * 4);
+    if (e == hipSuccess) e = fc.alloc((size_t)nblocks * 4);
     if (e != hipSuccess)
         return bb::fail(BB_ERR_NOMEM, std::string("bb_benjamini_hochberg: ") + hipGetErrorString(e));
     e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     if (e == hipSuccess)
         e = hipMemcpyAsync(p.p, p_values, (size_t)d * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(bh_local_kernel, dim3((unsigned)nblocks), dim3(kScanBlock), 0, st,
-                           (const double *)p.p, d, (double)n, (double *)q.p, (double *)bm.p);
-        hipLaunchKernelGGL(bh_blockscan_kernel, dim3(1), dim3(kScanBlock), 0, st, (double *)bm.p,
-                           nblocks);
-        hipLaunchKernelGGL(bh_apply_kernel, dim3((unsigned)nblocks), dim3(kScanBlock), 0, st,
-                           (double *)q.p, d, (const double *)bm.p);
-        e = hipGetLastError();
+        e = bb::launch(bh_local_kernel, dim3((unsigned)nblocks), dim3(kScanBlock), 0, st,
+                       (const double *)p.p, d, (double)n, (double *)q.p, (double *)bm.p,
+                       (int *)bc.p, (int *)fc.p);
+        if (e == hipSuccess)
+            e = bb::launch(bh_blockscan_kernel, dim3(1), dim3(kScanBlock), 0, st, (double *)bm.p,
+                           (int *)bc.p, nblocks);
+        if (e == hipSuccess)
+            e = bb::launch(bh_apply_kernel, dim3((unsigned)nblocks), dim3(kScanBlock), 0, st,
+                           (double *)q.p, d, (const double *)bm.p, (const int *)fc.p);
     }
     if (e == hipSuccess)
         e = hipMemcpyAsync(q_values, q.p, (size_t)d * 8, hipMemcpyDeviceToHost, st);
@@ -164,9 +232,8 @@ int bb_downsample(const float *yp1, int64_t n1, float *yp5i, int64_t n5, int dev
         e = hipMemcpyAsync(b.p, yp5i, (size_t)n5 * n5 * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         const unsigned g = (unsigned)((n5 - 1 + 15) / 16);
-        hipLaunchKernelGGL(downsample_kernel, dim3(g, g), dim3(256), 0, st, (const float *)a.p, n1,
-                           (float *)b.p, n5);
-        e = hipGetLastError();
+        e = bb::launch(downsample_kernel, dim3(g, g), dim3(256), 0, st, (const float *)a.p, n1,
+                       (float *)b.p, n5);
     }
     if (e == hipSuccess)
         e = hipMemcpyAsync(yp5i, b.p, (size_t)n5 * n5 * 4, hipMemcpyDeviceToHost, st);

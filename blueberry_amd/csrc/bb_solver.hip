@@ -7,8 +7,10 @@
 // Specification: docs/SPEC.md (build-authored; the reference has no solver,
 // SURVEY.md section 0).  Data layout and kernel design: DESIGN.md 3-4.
 #include <math.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -63,7 +65,8 @@ struct bb_solver {
     std::vector<void *> peer_mapped;        // arenas of all ranks as mapped here (own = peer_arena)
     std::vector<void *> peer_opened;        // the ones that came from hipIpcOpenMemHandle
     void *d_peer_table = nullptr;           // PeerTable<T>[2], one per parity
-    int *d_peer_status = nullptr;           // [0] sticky time-out flag
+    PeerState *d_peer_state = nullptr;      // sticky failure flag + last complete exchange
+    int peer_clock_khz = 100000;            // constant-rate clock behind wall_clock64()
     unsigned *d_peer_counter = nullptr;
     unsigned long long peer_seq = 0;        // iterations exchanged so far
     long long peer_limit_ticks = 0;
@@ -295,9 +298,9 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
                                              (int)(LDS)));                                      \
             s->defer_attr_done |= bit;                                                          \
         }                                                                                       \
-        hipLaunchKernelGGL(kern, grid, block, (size_t)(LDS), s->stream, units, X, s->d_udesc,   \
-                           s->d_wave_range, s->d_wave_slot, rowpart, colpart, s->d_stresspart,  \
-                           s->defer_cap_units);                                                 \
+        BB_HIP_CHECK(bb::launch(kern, grid, block, (size_t)(LDS), s->stream, units, X,          \
+                                s->d_udesc, s->d_wave_range, s->d_wave_slot, rowpart, colpart,  \
+                                s->d_stresspart, s->defer_cap_units));                          \
     } while (0)
 #define BB_LAUNCH(NTV, OPV)                                                                     \
     do {                                                                                        \
@@ -313,7 +316,6 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
     }
 #undef BB_LAUNCH
 #undef BB_LAUNCH2
-    BB_HIP_CHECK(hipGetLastError());
     return BB_OK;
 }
 
@@ -334,6 +336,7 @@ int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, doubl
     p.lr = (T)lr;
     p.peer = nullptr;
     p.peer_counter = s->d_peer_counter;
+    p.peer_state = s->d_peer_state;
     p.seq = 0;
     p.n_peers = 0;
     if (mode == kReducePeer) {
@@ -346,15 +349,14 @@ int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, doubl
         p.blk_ptr = s->d_s1_ptr;
         p.blk_chunk = s->d_s1_chunk;
         p.mode = kReducePartial;
-        hipLaunchKernelGGL((reduce_kernel<T, W>), dim3((unsigned)s->n_slices), dim3(256), 0, s->stream, p);
-        BB_HIP_CHECK(hipGetLastError());
+        BB_HIP_CHECK(bb::launch(reduce_kernel<T, W>, dim3((unsigned)s->n_slices), dim3(256), 0,
+                                s->stream, p));
     }
     p.blk_ptr = s->d_blk_ptr;
     p.blk_chunk = s->d_blk_chunk;
     p.mode = mode;
     const int grid = mode == kReduceStressOnly ? 1 : (int)s->L.n_blocks;
-    hipLaunchKernelGGL((reduce_kernel<T, W>), dim3(grid), dim3(256), 0, s->stream, p);
-    BB_HIP_CHECK(hipGetLastError());
+    BB_HIP_CHECK(bb::launch(reduce_kernel<T, W>, dim3(grid), dim3(256), 0, s->stream, p));
     return BB_OK;
 }
 
@@ -381,6 +383,24 @@ int check_ready(const bb_solver *s, const char *who) {
     if (!s->have_coords)
         return bb::fail(BB_ERR_STATE, std::string(who) + ": no coordinates set");
     return BB_OK;
+}
+
+// f64 <-> solver dtype conversions of n elements on the solver's stream.
+hipError_t widen(bb_solver *s, const void *in_T, double *out_f64, int64_t n) {
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    return s->dtype == BB_F32
+               ? bb::launch(T_to_f64_kernel<float>, grid, block, 0, s->stream, (const float *)in_T,
+                            out_f64, n)
+               : bb::launch(T_to_f64_kernel<double>, grid, block, 0, s->stream,
+                            (const double *)in_T, out_f64, n);
+}
+hipError_t narrow(bb_solver *s, const double *in_f64, void *out_T, int64_t n) {
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    return s->dtype == BB_F32
+               ? bb::launch(f64_to_T_kernel<float>, grid, block, 0, s->stream, in_f64,
+                            (float *)out_T, n)
+               : bb::launch(f64_to_T_kernel<double>, grid, block, 0, s->stream, in_f64,
+                            (double *)out_T, n);
 }
 
 template <typename T, bool W>
@@ -415,10 +435,9 @@ int set_wish_dense_t(bb_solver *s, const double *host, int64_t ld, int kind, dou
                                  (size_t)ld * sizeof(double), (size_t)cols_valid * sizeof(double),
                                  (size_t)rows_valid, hipMemcpyHostToDevice, s->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL((convert_units_kernel<T, W>), dim3((unsigned)(ue - ul)), dim3(256), 0,
-                               s->stream, stage, (T *)s->d_units, s->d_udesc, ul, i_start, n,
-                               kind, -1.0 / alpha);
-            e = hipGetLastError();
+            e = bb::launch(convert_units_kernel<T, W>, dim3((unsigned)(ue - ul)), dim3(256), 0,
+                           s->stream, stage, (T *)s->d_units, s->d_udesc, ul, i_start, n, kind,
+                           -1.0 / alpha);
         }
         if (e != hipSuccess)
             rc = bb::fail(BB_ERR_HIP, std::string("set_wish_dense: ") + hipGetErrorString(e));
@@ -448,6 +467,9 @@ struct PeerHandle {
     int32_t rank, world, dtype, device;
 };
 static_assert(sizeof(PeerHandle) <= BB_PEER_HANDLE_BYTES, "handle blob too small");
+static_assert(offsetof(PeerTable<float>, flag) == kMaxPeers * sizeof(void *) &&
+                  offsetof(PeerTable<double>, flag) == kMaxPeers * sizeof(void *),
+              "peer_wait_kernel takes the flag pointers as the second half of a PeerTable");
 constexpr uint64_t kPeerMagic = 0x6262706565723031ull;  // "bbpeer01"
 
 int64_t peer_flags_offset(const bb_solver *s) {
@@ -546,7 +568,7 @@ int bb_solver_destroy(bb_solver *s) {
     for (void *m : s->peer_opened) hipIpcCloseMemHandle(m);
     hipFree(s->peer_arena);
     hipFree(s->d_peer_table);
-    hipFree(s->d_peer_status);
+    hipFree(s->d_peer_state);
     hipFree(s->d_peer_counter);
     for (hipEvent_t e : s->ev) hipEventDestroy(e);
     hipFree(s->d_units);
@@ -567,6 +589,9 @@ int bb_solver_destroy(bb_solver *s) {
     hipFree(s->d_f64_tmp);
     if (s->own_stream && s->stream) hipStreamDestroy(s->stream);
     delete s;
+    // tear-down is best effort (a free can fail when a peer process has already gone
+    // away): whatever it left in the thread's error word is consumed here
+    (void)hipGetLastError();
     return BB_OK;
 }
 
@@ -652,20 +677,22 @@ int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *
                 e = hipMemcpyAsync(d_vals, vals + k0, (size_t)m * 8, hipMemcpyHostToDevice, s->stream);
             if (e != hipSuccess) break;
             const unsigned grid = (unsigned)((m + 255) / 256);
-#define BB_SCATTER(TT, WW)                                                                        \
-    hipLaunchKernelGGL((scatter_entries_kernel<TT, WW>), dim3(grid), dim3(256), 0, s->stream, d_rows, \
-                       d_cols, d_vals, m, d_map, nb, s->L.n_bins, s->u_begin, s->u_end,              \
-                       (TT *)s->d_units, kind, -1.0 / alpha, d_kr, d_ke, d_bad)
-            if (s->dtype == BB_F32) BB_SCATTER(float, true);
-            else if (s->wide) BB_SCATTER(double, true);
-            else BB_SCATTER(double, false);
+#define BB_SCATTER(TT, WW, PH)                                                                  \
+    bb::launch(scatter_entries_kernel<TT, WW>, dim3(grid), dim3(256), 0, s->stream, d_rows, d_cols, \
+               d_vals, m, d_map, nb, s->L.n_bins, s->u_begin, s->u_end, (TT *)s->d_units, kind,    \
+               -1.0 / alpha, d_kr, d_ke, d_bad, PH)
+            // clear / find the last entry per cell / store it (later chunks simply
+            // repeat this on top of earlier ones, so "last wins" holds across chunks)
+            for (int ph = 0; ph < 3 && e == hipSuccess; ++ph) {
+                if (s->dtype == BB_F32) e = BB_SCATTER(float, true, ph);
+                else if (s->wide) e = BB_SCATTER(double, true, ph);
+                else e = BB_SCATTER(double, false, ph);
+            }
 #undef BB_SCATTER
-            e = hipGetLastError();
             // the staging buffers are reused by the next chunk: stream order makes that safe
         }
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(&host_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+        if (e == hipSuccess) e = hipMemcpy(&host_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost);
     }
     hipFree(d_map);
     hipFree(d_bad);
@@ -694,14 +721,13 @@ int bb_solver_set_wish_from_coords(bb_solver *s, const double *xstar) {
     BB_HIP_CHECK(hipMemcpyAsync(s->d_f64_tmp, xstar, (size_t)s->L.n_bins * 3 * sizeof(double),
                                 hipMemcpyHostToDevice, s->stream));
     if (s->n_local > 0) {
-#define BB_GEN(TT, WW)                                                                          \
-    hipLaunchKernelGGL((gen_units_kernel<TT, WW>), dim3((unsigned)s->n_local), dim3(256), 0, s->stream, \
-                       s->d_f64_tmp, (TT *)s->d_units, s->d_udesc, s->L.n_bins)
+#define BB_GEN(TT, WW)                                                                         \
+    BB_HIP_CHECK(bb::launch(gen_units_kernel<TT, WW>, dim3((unsigned)s->n_local), dim3(256), 0,    \
+                            s->stream, s->d_f64_tmp, (TT *)s->d_units, s->d_udesc, s->L.n_bins))
         if (s->dtype == BB_F32) BB_GEN(float, true);
         else if (s->wide) BB_GEN(double, true);
         else BB_GEN(double, false);
 #undef BB_GEN
-        BB_HIP_CHECK(hipGetLastError());
     }
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     s->have_wish = true;
@@ -715,14 +741,7 @@ int bb_solver_set_coords(bb_solver *s, const double *xyz) {
     BB_HIP_CHECK(hipMemsetAsync(s->d_f64_tmp, 0, (size_t)n3 * sizeof(double), s->stream));
     BB_HIP_CHECK(hipMemcpyAsync(s->d_f64_tmp, xyz, (size_t)s->L.n_bins * 3 * sizeof(double),
                                 hipMemcpyHostToDevice, s->stream));
-    const unsigned grid = (unsigned)((n3 + 255) / 256);
-    if (s->dtype == BB_F32)
-        hipLaunchKernelGGL(f64_to_T_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
-                           s->d_f64_tmp, (float *)s->d_X, n3);
-    else
-        hipLaunchKernelGGL(f64_to_T_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
-                           s->d_f64_tmp, (double *)s->d_X, n3);
-    BB_HIP_CHECK(hipGetLastError());
+    BB_HIP_CHECK(narrow(s, s->d_f64_tmp, s->d_X, n3));
     BB_HIP_CHECK(hipMemsetAsync(s->d_V, 0, (size_t)n3 * bb::elem_size(s->dtype), s->stream));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     s->have_coords = true;
@@ -736,14 +755,7 @@ int bb_solver_get_coords(bb_solver *s, double *xyz) {
     if (!s->have_coords) return bb::fail(BB_ERR_STATE, "bb_solver_get_coords: no coordinates set");
     BB_TRY(bb::enter_device(s->device));
     const int64_t n3 = s->L.n_pad * 3;
-    const unsigned grid = (unsigned)((n3 + 255) / 256);
-    if (s->dtype == BB_F32)
-        hipLaunchKernelGGL(T_to_f64_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
-                           (const float *)s->d_X, s->d_f64_tmp, n3);
-    else
-        hipLaunchKernelGGL(T_to_f64_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
-                           (const double *)s->d_X, s->d_f64_tmp, n3);
-    BB_HIP_CHECK(hipGetLastError());
+    BB_HIP_CHECK(widen(s, s->d_X, s->d_f64_tmp, n3));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     BB_HIP_CHECK(hipMemcpy(xyz, s->d_f64_tmp, (size_t)s->L.n_bins * 3 * sizeof(double),
                            hipMemcpyDeviceToHost));
@@ -802,14 +814,13 @@ int bb_solver_apply(bb_solver *s, double lr) {
     const int64_t n3 = s->L.n_pad * 3;
     const unsigned grid = (unsigned)((n3 + 255) / 256);
     if (s->dtype == BB_F32)
-        hipLaunchKernelGGL(apply_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
-                           (float *)s->d_X, (float *)s->d_V, (const float *)s->d_exch, n3,
-                           (float)lr, (float)s->momentum, s->d_stress_hist + s->hist_n);
+        BB_HIP_CHECK(bb::launch(apply_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
+                                (float *)s->d_X, (float *)s->d_V, (const float *)s->d_exch, n3,
+                                (float)lr, (float)s->momentum, s->d_stress_hist + s->hist_n));
     else
-        hipLaunchKernelGGL(apply_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
-                           (double *)s->d_X, (double *)s->d_V, (const double *)s->d_exch, n3, lr,
-                           s->momentum, s->d_stress_hist + s->hist_n);
-    BB_HIP_CHECK(hipGetLastError());
+        BB_HIP_CHECK(bb::launch(apply_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
+                                (double *)s->d_X, (double *)s->d_V, (const double *)s->d_exch, n3,
+                                lr, s->momentum, s->d_stress_hist + s->hist_n));
     s->hist_n++;
     s->grad_pending = false;
     return BB_OK;
@@ -840,6 +851,33 @@ int bb_solver_comm_init(bb_solver *s, const void *unique_id) {
         s->comm = nullptr;
         return bb::fail(BB_ERR_HIP, std::string("ncclCommInitRank: ") + R.GetErrorString(rc));
     }
+    return BB_OK;
+}
+
+int bb_solver_comm_abort(bb_solver *s) {
+    BB_REQUIRE(s != nullptr, "bb_solver_comm_abort: solver is NULL");
+    if (!s->comm) return BB_OK;
+    const bb::Rccl &R = bb::rccl();
+    bb::Rccl::Comm c = s->comm;
+    s->comm = nullptr;
+    s->grad_pending = false;
+    // ncclCommAbort ends the communicator's in-flight kernels, so a stream that is
+    // stuck behind a collective a peer never joined drains again
+    const int rc = R.CommAbort ? R.CommAbort(c) : R.CommDestroy(c);
+    if (rc != bb::Rccl::kSuccess)
+        return bb::fail(BB_ERR_HIP, std::string("ncclCommAbort: ") + R.GetErrorString(rc));
+    return BB_OK;
+}
+
+int bb_solver_comm_world(const bb_solver *s, int *world) {
+    BB_REQUIRE(s != nullptr && world != nullptr, "bb_solver_comm_world: NULL argument");
+    *world = 0;
+    if (!s->comm) return bb::fail(BB_ERR_STATE, "bb_solver_comm_world: no communicator");
+    const bb::Rccl &R = bb::rccl();
+    if (!R.CommCount) return bb::fail(BB_ERR_HIP, "bb_solver_comm_world: ncclCommCount missing");
+    const int rc = R.CommCount(s->comm, world);
+    if (rc != bb::Rccl::kSuccess)
+        return bb::fail(BB_ERR_HIP, std::string("ncclCommCount: ") + R.GetErrorString(rc));
     return BB_OK;
 }
 
@@ -958,23 +996,37 @@ int bb_solver_peer_connect(bb_solver *s, const void *handles) {
         }
     }
     BB_TRY(s->dtype == BB_F32 ? build_peer_tables<float>(s) : build_peer_tables<double>(s));
-    BB_TRY(dev_alloc(&s->d_peer_status, 1));
+    BB_TRY(dev_alloc(&s->d_peer_state, 1));
     BB_TRY(dev_alloc(&s->d_peer_counter, 1));
-    BB_HIP_CHECK(hipMemset(s->d_peer_status, 0, sizeof(int)));
+    BB_HIP_CHECK(hipMemset(s->d_peer_state, 0, sizeof(PeerState)));
     BB_HIP_CHECK(hipMemset(s->d_peer_counter, 0, sizeof(unsigned)));
+    // ticks of wall_clock64(): ask the runtime, fall back to gfx9's 100 MHz.  The query
+    // is allowed to fail (older runtimes); its error is consumed here, on the spot.
     int khz = 0;
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->device) != hipSuccess || khz <= 0)
-        khz = 100000;  // gfx9: 100 MHz
-    (void)hipGetLastError();
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, s->device) != hipSuccess) {
+        (void)hipGetLastError();
+        khz = 0;
+    }
+    s->peer_clock_khz = khz > 0 ? khz : 100000;
     long long ms = 10000;
     if (const char *env = getenv("BB_PEER_TIMEOUT_MS")) {
         const long long v = atoll(env);
         if (v > 0) ms = v;
     }
-    s->peer_limit_ticks = ms * khz;
+    s->peer_limit_ticks = ms * s->peer_clock_khz;
     s->peer_seq = 0;
     s->peer_connected = true;
     BB_HIP_CHECK(hipDeviceSynchronize());
+    return BB_OK;
+}
+
+int bb_solver_peer_set_timeout(bb_solver *s, int64_t milliseconds) {
+    BB_REQUIRE(s != nullptr, "bb_solver_peer_set_timeout: solver is NULL");
+    BB_REQUIRE(milliseconds > 0 && milliseconds <= 3600000,
+               "bb_solver_peer_set_timeout: need 0 < ms <= 3600000");
+    if (!s->peer_connected)
+        return bb::fail(BB_ERR_STATE, "bb_solver_peer_set_timeout: not connected");
+    s->peer_limit_ticks = (long long)milliseconds * s->peer_clock_khz;
     return BB_OK;
 }
 
@@ -982,14 +1034,18 @@ int bb_solver_peer_status(bb_solver *s, int *status) {
     BB_REQUIRE(s != nullptr, "bb_solver_peer_status: solver is NULL");
     if (!s->peer_connected) return bb::fail(BB_ERR_STATE, "bb_solver_peer_status: not connected");
     BB_TRY(bb::enter_device(s->device));
-    int st = 0;
+    PeerState st;
+    memset(&st, 0, sizeof(st));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
-    BB_HIP_CHECK(hipMemcpy(&st, s->d_peer_status, sizeof(int), hipMemcpyDeviceToHost));
-    if (status) *status = st;
-    if (st != 0)
+    BB_HIP_CHECK(hipMemcpy(&st, s->d_peer_state, sizeof(st), hipMemcpyDeviceToHost));
+    if (status) *status = st.status;
+    if (st.status != 0)
         return bb::fail(BB_ERR_STATE,
                         "peer exchange: a rank did not deliver its partial within the time limit "
-                        "(BB_PEER_TIMEOUT_MS); coordinates were left at the last completed step");
+                        "(BB_PEER_TIMEOUT_MS), or reported its own failure; this rank's "
+                        "coordinates were left at its last completed step (" +
+                            std::to_string(st.verdict) + " of " + std::to_string(s->peer_seq) +
+                            " exchanges) and every peer has been told to stop");
     return BB_OK;
 }
 
@@ -1017,19 +1073,23 @@ int bb_solver_iterate_peer(bb_solver *s, int64_t iters, double lr) {
                             (int64_t)(s->peer_seq & 1) * s->world * s->peer_slot_elems * es;
         const unsigned long long *flags =
             (const unsigned long long *)((const char *)s->peer_arena + peer_flags_offset(s));
+        // the flag pointers are the second half of a PeerTable (same for both parities)
+        unsigned long long *const *poison =
+            (unsigned long long *const *)((const char *)s->d_peer_table + kMaxPeers * sizeof(void *));
+        BB_HIP_CHECK(bb::launch(peer_wait_kernel, dim3(1), dim3(64), 0, s->stream, flags, s->world,
+                                s->peer_seq, s->d_peer_state, poison, s->peer_limit_ticks));
         if (s->dtype == BB_F32)
-            hipLaunchKernelGGL(peer_apply_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
-                               (float *)s->d_X, (float *)s->d_V, (const float *)arena, flags,
-                               s->world, s->peer_slot_elems, n3, (float)lr, (float)s->momentum,
-                               s->d_stress_hist + s->hist_n, s->peer_seq, s->d_peer_status,
-                               s->peer_limit_ticks);
+            BB_HIP_CHECK(bb::launch(peer_apply_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
+                                    (float *)s->d_X, (float *)s->d_V, (const float *)arena,
+                                    s->world, s->peer_slot_elems, n3, (float)lr,
+                                    (float)s->momentum, s->d_stress_hist + s->hist_n, s->peer_seq,
+                                    (const PeerState *)s->d_peer_state));
         else
-            hipLaunchKernelGGL(peer_apply_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
-                               (double *)s->d_X, (double *)s->d_V, (const double *)arena, flags,
-                               s->world, s->peer_slot_elems, n3, lr, s->momentum,
-                               s->d_stress_hist + s->hist_n, s->peer_seq, s->d_peer_status,
-                               s->peer_limit_ticks);
-        BB_HIP_CHECK(hipGetLastError());
+            BB_HIP_CHECK(bb::launch(peer_apply_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
+                                    (double *)s->d_X, (double *)s->d_V, (const double *)arena,
+                                    s->world, s->peer_slot_elems, n3, lr, s->momentum,
+                                    s->d_stress_hist + s->hist_n, s->peer_seq,
+                                    (const PeerState *)s->d_peer_state));
         s->hist_n++;
     }
     return BB_OK;
@@ -1063,14 +1123,7 @@ int bb_solver_read_exchange(bb_solver *s, double *host, int64_t n) {
     BB_TRY(bb::enter_device(s->device));
     double *tmp = nullptr;
     BB_TRY(dev_alloc(&tmp, n));
-    const unsigned grid = (unsigned)((n + 255) / 256);
-    if (s->dtype == BB_F32)
-        hipLaunchKernelGGL(T_to_f64_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
-                           (const float *)s->d_exch, tmp, n);
-    else
-        hipLaunchKernelGGL(T_to_f64_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
-                           (const double *)s->d_exch, tmp, n);
-    hipError_t e = hipGetLastError();
+    hipError_t e = widen(s, s->d_exch, tmp, n);
     if (e == hipSuccess)
         e = hipMemcpyAsync(host, tmp, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
@@ -1088,16 +1141,7 @@ int bb_solver_write_exchange(bb_solver *s, const double *host, int64_t n) {
     BB_TRY(dev_alloc(&tmp, n));
     hipError_t e = hipMemcpyAsync(tmp, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice,
                                   s->stream);
-    if (e == hipSuccess) {
-        const unsigned grid = (unsigned)((n + 255) / 256);
-        if (s->dtype == BB_F32)
-            hipLaunchKernelGGL(f64_to_T_kernel<float>, dim3(grid), dim3(256), 0, s->stream, tmp,
-                               (float *)s->d_exch, n);
-        else
-            hipLaunchKernelGGL(f64_to_T_kernel<double>, dim3(grid), dim3(256), 0, s->stream, tmp,
-                               (double *)s->d_exch, n);
-        e = hipGetLastError();
-    }
+    if (e == hipSuccess) e = narrow(s, tmp, s->d_exch, n);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     hipFree(tmp);
     if (e != hipSuccess)
@@ -1117,29 +1161,13 @@ int bb_solver_matvec_sq(bb_solver *s, const double *x, double *y) {
     hipError_t e = hipMemsetAsync(s->d_f64_tmp, 0, (size_t)n3 * 8, s->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(s->d_f64_tmp, x, (size_t)s->L.n_bins * 24, hipMemcpyHostToDevice, s->stream);
-    if (e == hipSuccess) {
-        const unsigned grid = (unsigned)((n3 + 255) / 256);
-        if (s->dtype == BB_F32)
-            hipLaunchKernelGGL(f64_to_T_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
-                               s->d_f64_tmp, (float *)d_in, n3);
-        else
-            hipLaunchKernelGGL(f64_to_T_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
-                               s->d_f64_tmp, (double *)d_in, n3);
-        e = hipGetLastError();
-    }
+    if (e == hipSuccess) e = narrow(s, s->d_f64_tmp, d_in, n3);
     int rc = BB_OK;
     if (e != hipSuccess) rc = bb::fail(BB_ERR_HIP, std::string("bb_solver_matvec_sq: ") + hipGetErrorString(e));
     if (rc == BB_OK) rc = launch_grad(s, kOpMatvec2, d_in);
     if (rc == BB_OK) rc = launch_reduce(s, kReduceExchange, 0.0, nullptr, 1.0);
     if (rc == BB_OK) {
-        const unsigned grid = (unsigned)((n3 + 255) / 256);
-        if (s->dtype == BB_F32)
-            hipLaunchKernelGGL(T_to_f64_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
-                               (const float *)s->d_exch, s->d_f64_tmp, n3);
-        else
-            hipLaunchKernelGGL(T_to_f64_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
-                               (const double *)s->d_exch, s->d_f64_tmp, n3);
-        e = hipGetLastError();
+        e = widen(s, s->d_exch, s->d_f64_tmp, n3);
         if (e == hipSuccess)
             e = hipMemcpyAsync(y, s->d_f64_tmp, (size_t)s->L.n_bins * 24, hipMemcpyDeviceToHost,
                                s->stream);
@@ -1180,6 +1208,28 @@ int bb_solver_sync(bb_solver *s) {
     BB_TRY(bb::enter_device(s->device));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     return BB_OK;
+}
+
+int bb_solver_sync_timeout(bb_solver *s, int64_t milliseconds) {
+    BB_REQUIRE(s != nullptr, "bb_solver_sync_timeout: solver is NULL");
+    BB_REQUIRE(milliseconds >= 0, "bb_solver_sync_timeout: milliseconds < 0");
+    BB_TRY(bb::enter_device(s->device));
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s->stream);
+        if (e == hipSuccess) return BB_OK;
+        if (e != hipErrorNotReady)
+            return bb::fail(BB_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(e));
+        (void)hipGetLastError();   // "not ready" is an answer, not a failure
+        timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        const int64_t ms = (t.tv_sec - t0.tv_sec) * 1000 + (t.tv_nsec - t0.tv_nsec) / 1000000;
+        if (ms >= milliseconds)
+            return bb::fail(BB_ERR_STATE, "bb_solver_sync_timeout: the stream did not drain within " +
+                                              std::to_string(milliseconds) + " ms");
+        usleep(50);
+    }
 }
 
 int bb_solver_set_timing(bb_solver *s, int enabled) {
@@ -1242,20 +1292,14 @@ int bb_solver_measure_stream_read(bb_solver *s, int launches, double *ms_avg) {
     BB_HIP_CHECK(hipEventCreate(&e0));
     BB_HIP_CHECK(hipEventCreate(&e1));
     auto launch = [&]() {
-        if (s->nontemporal)
-            hipLaunchKernelGGL((stream_read_kernel<true>), dim3(s->n_waves / 4), dim3(256), 0,
-                               s->stream, (const float4 *)s->d_units, s->d_wave_range,
-                               (float *)s->d_f64_tmp);
-        else
-            hipLaunchKernelGGL((stream_read_kernel<false>), dim3(s->n_waves / 4), dim3(256), 0,
-                               s->stream, (const float4 *)s->d_units, s->d_wave_range,
-                               (float *)s->d_f64_tmp);
+        return bb::launch(s->nontemporal ? stream_read_kernel<true> : stream_read_kernel<false>,
+                          dim3(s->n_waves / 4), dim3(256), 0, s->stream,
+                          (const float4 *)s->d_units, s->d_wave_range, (float *)s->d_f64_tmp);
     };
-    launch();  // warm-up
+    BB_HIP_CHECK(launch());  // warm-up
     BB_HIP_CHECK(hipEventRecord(e0, s->stream));
-    for (int k = 0; k < launches; ++k) launch();
+    for (int k = 0; k < launches; ++k) BB_HIP_CHECK(launch());
     BB_HIP_CHECK(hipEventRecord(e1, s->stream));
-    BB_HIP_CHECK(hipGetLastError());
     BB_HIP_CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
     BB_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));

@@ -24,6 +24,7 @@
 
 #include <type_traits>
 
+#include "bb_ablate.h"
 #include "blueberry_hip.h"
 
 namespace {
@@ -213,11 +214,10 @@ __device__ __forceinline__ void pair_step(const typename Traits<T>::Vec &drow, T
     if constexpr (sizeof(T) == 4) {
         rinv = __builtin_amdgcn_rsqf(d2);
         dist = d2 * rinv;
-    } else {
-#ifdef BB_ABL_F64_LIBM        // timing experiment: library sqrt + IEEE divide (~55 fp64 ops)
+    } else if constexpr (abl::kF64Libm) {
         dist = sqrt(d2);
         rinv = 1.0 / dist;
-#else
+    } else {
         // v_rsq_f64 seed, two Newton steps on 1/sqrt, one on sqrt: ~12 fp64 ops,
         // both results within 1-2 ulp (the parity tolerance is 1e-12)
         T r = __builtin_amdgcn_rsq(d2);
@@ -227,7 +227,6 @@ __device__ __forceinline__ void pair_step(const typename Traits<T>::Vec &drow, T
         dist = d2 * r;
         dist = fma(T(0.5) * r, fma(-dist, dist, d2), dist);
         rinv = r;
-#endif
     }
     const T res = delta > T(0) ? dist - delta : T(0);
     s = fma(res, res, s);
@@ -340,17 +339,14 @@ __device__ __forceinline__ void pair_step2(f32x2 delta, f32x2 xi, f32x2 yi, f32x
     const f32x2 dx = xi - st.x[K][H][0], dy = yi - st.x[K][H][1], dz = zi - st.x[K][H][2];
     const f32x2 d2 = dx * dx + (dy * dy + (dz * dz + eps2));  // SPEC 2.2: |d|^2 + eps^2
     f32x2 rinv;
-#ifdef BB_ABL_NORSQ  // timing experiment: wrong results
-    rinv = d2 * eps2;
-#else
-    rinv.x = __builtin_amdgcn_rsqf(d2.x);
-    rinv.y = __builtin_amdgcn_rsqf(d2.y);
-#endif
-#ifdef BB_ABL_NOMASK
-    const f32x2 res = (d2 * rinv - delta);
-#else
-    const f32x2 res = (d2 * rinv - delta) * weight01(delta);  // (dist - delta) or 0
-#endif
+    if constexpr (abl::kNoRsq) {
+        rinv = d2 * eps2;
+    } else {
+        rinv.x = __builtin_amdgcn_rsqf(d2.x);
+        rinv.y = __builtin_amdgcn_rsqf(d2.y);
+    }
+    f32x2 res = d2 * rinv - delta;
+    if constexpr (!abl::kNoMask) res *= weight01(delta);  // (dist - delta) or 0
     s2 += res * res;
     const f32x2 coef = res * rinv;
     if constexpr (FIRST) {
@@ -358,11 +354,11 @@ __device__ __forceinline__ void pair_step2(f32x2 delta, f32x2 xi, f32x2 yi, f32x
     } else {
         rx += coef * dx; ry += coef * dy; rz += coef * dz;
     }
-#ifndef BB_ABL_NOCOL
-    st.g[K][H][0] -= coef * dx;
-    st.g[K][H][1] -= coef * dy;
-    st.g[K][H][2] -= coef * dz;
-#endif
+    if constexpr (!abl::kNoCol) {
+        st.g[K][H][0] -= coef * dx;
+        st.g[K][H][1] -= coef * dy;
+        st.g[K][H][2] -= coef * dz;
+    }
 }
 
 // d[] holds the unit's 8 wave-loads in row order: d[2*r + k] = row r, load k.
@@ -395,21 +391,19 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&x
         d[2 * r + 1] = stream_load<NT>(next + (2 * r + 1) * 64);
         rx += qx; ry += qy; rz += qz;
         float gx = rx.x + rx.y, gy = ry.x + ry.y, gz = rz.x + rz.y;
-#ifndef BB_ABL_NODPP
-        wave_sum_hi3(gx, gy, gz);
-#endif
+        if constexpr (!abl::kNoDpp) wave_sum_hi3(gx, gy, gz);
         const float mine = comp == 0 ? gx : (comp == 1 ? gy : gz);
         keep = (slot >= 3 * r && slot < 3 * r + 3) ? mine : keep;
     }
-#ifndef BB_ABL_NOSTORE
-    // DEFER: both are issued for every unit and exactly one of them lands -- the LDS
-    // slot is a dummy word while the unit is stored directly, the store's lanes are all
-    // out of range (free) while the unit is parked (see the kernel)
-    if constexpr (DEFER) row_lds[stage_idx] = keep;
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(keep), row_rsrc, row_voff, 0, 0);
-#else
-    asm volatile("" ::"v"(keep));
-#endif
+    if constexpr (abl::kNoStore) {
+        asm volatile("" ::"v"(keep));
+    } else {
+        // DEFER: both are issued for every unit and exactly one of them lands -- the LDS
+        // slot is a dummy word while the unit is stored directly, the store's lanes are
+        // all out of range (free) while the unit is parked (see the kernel)
+        if constexpr (DEFER) row_lds[stage_idx] = keep;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(keep), row_rsrc, row_voff, 0, 0);
+    }
     stress += (double)(s2.x + s2.y);
 }
 
@@ -587,11 +581,8 @@ __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
             T v;
             __device__ __forceinline__ T get(int q) const { return lane_value(v, q); }
         };
-#ifdef BB_ABL_XROW_VECTOR
-        using XRow = XRowV;
-#else
-        using XRow = typename std::conditional<Lay<T, W>::SCALAR_XROW, XRowS, XRowV>::type;
-#endif
+        using XRow = typename std::conditional<Lay<T, W>::SCALAR_XROW && !abl::kXrowVector, XRowS,
+                                               XRowV>::type;
         auto xrow_load = [&](int i0) __attribute__((always_inline)) {
             XRow x;
             if constexpr (std::is_same<XRow, XRowS>::value) {
@@ -637,16 +628,11 @@ __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
                 row_voff = lane == 63 ? (unsigned)(u - ua) * kRowBytes : kDropOffset;
             }
             if constexpr (sizeof(T) == 4) {
-#ifdef BB_ABL_XROW_VECTOR
-                float xs12[12];
+                float xs12[12];             // scalar registers in the product build
 #pragma unroll
-                for (int q = 0; q < 12; ++q) xs12[q] = lane_value(xr.v, q);
+                for (int q = 0; q < 12; ++q) xs12[q] = xr.get(q);
                 process_unit_f32<NT, OP, DEFER>(d, xs12, unit_ptr<T>(units, un, lane), st, stress,
                                                 row_rsrc, row_voff, stage_slot);
-#else
-                process_unit_f32<NT, OP, DEFER>(d, xr.v, unit_ptr<T>(units, un, lane), st, stress,
-                                                row_rsrc, row_voff, stage_slot);
-#endif
             }
             else
                 process_unit<T, W, NT, OP>(d, xr, unit_ptr<T>(units, un, lane), st.xj, st.gc, stress,
@@ -718,6 +704,19 @@ struct PeerTable {
     T *dst[kMaxPeers];
     unsigned long long *flag[kMaxPeers];
 };
+// Health of this rank's peer exchange, in device memory.  `status` is sticky: once a
+// wait has failed (time limit, or a peer reported its own failure) every later launch
+// of this rank leaves X alone and pushes nothing.  `verdict` is the sequence number of
+// the last exchange whose R partials all arrived: written by ONE wave
+// (peer_wait_kernel), read by every workgroup of the update, so a launch is applied
+// by all of its workgroups or by none.
+struct PeerState {
+    int status;
+    int pad;
+    unsigned long long verdict;
+};
+// Flag value a failed rank leaves on every peer: their waits end at once and fail too.
+constexpr unsigned long long kPeerPoison = ~0ull;
 
 template <typename T>
 struct ReduceParams {
@@ -733,6 +732,7 @@ struct ReduceParams {
     T *__restrict__ part_out;                // partial mode: CH elements per workgroup
     const PeerTable<T> *__restrict__ peer;   // peer mode: destinations, in device memory
     unsigned *__restrict__ peer_counter;     // peer mode: workgroups done (last one raises flags)
+    const PeerState *peer_state;             // peer mode: a failed rank pushes nothing
     unsigned long long seq;                  // peer mode: value the flags take
     int n_peers;
     double *__restrict__ stress_out;         // apply / stress-only: where the stress goes
@@ -749,6 +749,11 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     __shared__ __attribute__((aligned(16))) T push_stage[CH];   // peer mode only
+    // peer mode: once this rank's exchange has failed it stops delivering (the status
+    // word is only ever written by peer_wait_kernel, i.e. between launches: uniform)
+    const bool peer_live =
+        p.mode != kReducePeer ||
+        __hip_atomic_load(&p.peer_state->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
     if (p.mode != kReduceStressOnly) {
         const int64_t k0 = p.blk_ptr[b], k1 = p.blk_ptr[b + 1];
         T acc[NE];
@@ -798,7 +803,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
                 }
             }
         }
-        if (p.mode == kReducePeer) {
+        if (p.mode == kReducePeer && peer_live) {
             // the block's 3*vw values go out as 16-byte stores, 1 KiB per wave
             // instruction and peer: what crosses xGMI is long contiguous bursts
             typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
@@ -831,7 +836,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
                 p.exch[3 * p.n_pad + 1] = (T)(S - (double)hi);
             } else if (p.mode == kReducePeer) {
                 const T hi = (T)S, lo = (T)(S - (double)hi);
-                for (int q = 0; q < p.n_peers; ++q) {
+                for (int q = 0; q < (peer_live ? p.n_peers : 0); ++q) {
                     p.peer->dst[q][3 * p.n_pad] = hi;
                     p.peer->dst[q][3 * p.n_pad + 1] = lo;
                 }
@@ -840,7 +845,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
             }
         }
     }
-    if (p.mode == kReducePeer) {
+    if (p.mode == kReducePeer && peer_live) {
         // Every workgroup makes its stores visible system-wide and checks in; the
         // last one to do so raises this rank's flag on every peer (release).
         __shared__ int last;
@@ -859,40 +864,57 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
 }
 
 
-// Peer exchange, receiving side: wait until every source rank's flag has reached
-// `seq`, then X <- X + (mu V - lr * sum over ranks, in rank order).  The wait is
-// bounded: past `limit` ticks of the constant-rate clock the status word is set,
-// and every later launch returns at once without touching X ("sticky" failure,
-// reported by bb_solver_peer_status).  `arena` is this parity's first slot.
-template <typename T>
-__global__ __launch_bounds__(256) void peer_apply_kernel(
-    T *__restrict__ X, T *__restrict__ V, const T *arena, const unsigned long long *flags,
-    int world, int64_t slot_elems, int64_t n3, T lr, T mu, double *stress_out,
-    unsigned long long seq, int *status, long long limit) {
-    __shared__ int ok;
-    const int tid = threadIdx.x;
-    if (tid == 0) ok = 1;
-    __syncthreads();
-    if (tid < world) {
-        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            ok = 0;
-        } else {
-            const long long t0 = wall_clock64();
-            while (__hip_atomic_load(flags + 8 * tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) <
-                   seq) {
-                if (wall_clock64() - t0 > limit) {
-                    atomicExch(status, 1);
-                    ok = 0;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
+// Peer exchange, receiving side, part 1: ONE wave waits until every source rank's flag
+// has reached `seq` and publishes the outcome for the whole update launch that follows
+// (state->verdict = seq).  The wait is bounded: past `limit` ticks of the constant-rate
+// clock -- or when a peer has left its poison flag -- the sticky status word is set,
+// the verdict is withheld, and this rank's own flag on every peer is poisoned so that
+// nobody goes on consuming partials computed from coordinates that no longer move.
+// Deciding in one place is what keeps X whole: with every workgroup of the update
+// polling for itself, some could time out while later ones saw the flags arrive.
+__global__ __launch_bounds__(64) void peer_wait_kernel(const unsigned long long *flags, int world,
+                                                       unsigned long long seq, PeerState *state,
+                                                       unsigned long long *const *poison_flags,
+                                                       long long limit) {
+    const int lane = threadIdx.x;
+    bool all_ok = false;
+    if (__hip_atomic_load(&state->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        // The whole wave polls together until EVERY flag is there: a lane whose flag
+        // has arrived keeps reading it, so a poison that lands later is still seen.
+        const long long t0 = wall_clock64();
+        for (;;) {
+            const unsigned long long f =
+                lane < world ? __hip_atomic_load(flags + 8 * lane, __ATOMIC_ACQUIRE,
+                                                 __HIP_MEMORY_SCOPE_SYSTEM)
+                             : seq;
+            if (__ballot(f == kPeerPoison) != 0) break;
+            if (__ballot(f >= seq) == __ballot(1)) { all_ok = true; break; }
+            if (__ballot(wall_clock64() - t0 > limit) != 0) break;   // wave-uniform exits only
+            __builtin_amdgcn_s_sleep(4);
         }
     }
-    __syncthreads();
-    if (!ok) return;
-    // The pollers' acquire + the barrier order every thread's loads after the
-    // peers' stores; the arena is uncached memory, read past L1/L2 (sc0 sc1).
+    if (all_ok) {
+        if (lane == 0)
+            __hip_atomic_store(&state->verdict, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (lane == 0) atomicExch(&state->status, 1);
+        if (lane < world)
+            __hip_atomic_store(poison_flags[lane], kPeerPoison, __ATOMIC_RELEASE,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Part 2: X <- X + (mu V - lr * sum over ranks, in rank order), only if the wait
+// before it published this launch's sequence number (every workgroup reads the same
+// word, so the step is applied whole or not at all).  `arena` is this parity's first
+// slot; it is uncached memory, read past L1/L2.
+template <typename T>
+__global__ __launch_bounds__(256) void peer_apply_kernel(
+    T *__restrict__ X, T *__restrict__ V, const T *arena, int world, int64_t slot_elems,
+    int64_t n3, T lr, T mu, double *stress_out, unsigned long long seq, const PeerState *state) {
+    if (__hip_atomic_load(&state->verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq)
+        return;
+    const int tid = threadIdx.x;
     const int64_t e = (int64_t)blockIdx.x * 256 + tid;
     if (e < n3) {
         // all slots are requested before the first add (one memory round trip per
@@ -917,7 +939,10 @@ __global__ __launch_bounds__(256) void peer_apply_kernel(
     if (e == 0) {
         double S = 0.0;
         for (int r = 0; r < world; ++r)
-            S += (double)arena[r * slot_elems + n3] + (double)arena[r * slot_elems + n3 + 1];
+            S += (double)__hip_atomic_load(arena + r * slot_elems + n3, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM) +
+                 (double)__hip_atomic_load(arena + r * slot_elems + n3 + 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_SYSTEM);
         *stress_out = S;
     }
 }
@@ -971,14 +996,22 @@ __global__ __launch_bounds__(256) void convert_units_kernel(
 // Sparse (i, j, value) entries -> resident units (blocked-sparse input).  The
 // units were zeroed ("no constraint") first.  tilemap[I * n_blocks + J] is the
 // tile's index in the global list or -1.
+//
+// A bin pair that occurs more than once keeps its LAST entry, as in the reference's
+// scatter (`matrix[j*d+k] = ...` in file order, blueberry/datatypes.pyx:110-116) and
+// in bb_contactmap_scatter.  Three passes over the entries, nothing the size of the
+// matrix: `phase` 0 clears every cell an entry names, 1 records the highest entry
+// index + 1 per cell (integer atomicMax on the cell's own bits, which the clear left
+// at 0), 2 lets that entry alone store its value.
 template <typename T, bool W>
 __global__ __launch_bounds__(256) void scatter_entries_kernel(
     const int64_t *__restrict__ rows, const int64_t *__restrict__ cols,
     const double *__restrict__ vals, int64_t nnz, const int32_t *__restrict__ tilemap,
     int64_t n_blocks, int64_t n_bins, int64_t u_begin, int64_t u_end, T *__restrict__ units,
     int kind, double neg_inv_alpha, const double *__restrict__ kr,
-    const double *__restrict__ krexp, int *__restrict__ bad) {
+    const double *__restrict__ krexp, int *__restrict__ bad, int phase) {
     constexpr int VW = Lay<T, W>::VW, RPU = Lay<T, W>::RPU, UPT = VW / RPU;
+    using Bits = typename std::conditional<sizeof(T) == 4, unsigned int, unsigned long long>::type;
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= nnz) return;
     int64_t i = rows[k], j = cols[k];
@@ -991,6 +1024,16 @@ __global__ __launch_bounds__(256) void scatter_entries_kernel(
     const int64_t ri = i - I * VW;
     const int64_t u = (int64_t)t * UPT + ri / RPU;
     if (u < u_begin || u >= u_end) return;  // another rank's unit
+    T *cell = units + (u - u_begin) * (RPU * VW) + (ri % RPU) * VW + (j - J * VW);
+    if (phase == 0) {
+        *reinterpret_cast<Bits *>(cell) = 0;
+        return;
+    }
+    if (phase == 1) {
+        atomicMax(reinterpret_cast<Bits *>(cell), (Bits)(k + 1));
+        return;
+    }
+    if (*reinterpret_cast<const Bits *>(cell) != (Bits)(k + 1)) return;   // a later entry won
     double v = vals[k];
     // KR balancing + observed/expected, the element-wise form of the loop at
     // reference datatypes.pyx:166-169 (same operation order)
@@ -1001,7 +1044,7 @@ __global__ __launch_bounds__(256) void scatter_entries_kernel(
     else if (kind == BB_KIND_COUNTS)
         v = pow(v, neg_inv_alpha);
     if (sizeof(T) == 4 && v < 1e-30) v = 0.0;
-    units[(u - u_begin) * (RPU * VW) + (ri % RPU) * VW + (j - J * VW)] = (T)v;
+    *cell = (T)v;
 }
 
 // delta_ij = |x*_i - x*_j| generated in place (synthetic inputs).

@@ -226,6 +226,25 @@ class HipEngine(object):
         _lib.check(self._lib.bb_solver_iterate_peer(self._h, int(iters), float(lr)),
                    "bb_solver_iterate_peer")
 
+    def sync_timeout(self, milliseconds):
+        """sync() that raises RuntimeError if the stream has not drained in time."""
+        _lib.check(self._lib.bb_solver_sync_timeout(self._h, int(milliseconds)),
+                   "bb_solver_sync_timeout")
+
+    def comm_abort(self):
+        _lib.check(self._lib.bb_solver_comm_abort(self._h), "bb_solver_comm_abort")
+
+    def peer_set_timeout(self, milliseconds):
+        _lib.check(self._lib.bb_solver_peer_set_timeout(self._h, int(milliseconds)),
+                   "bb_solver_peer_set_timeout")
+
+    def comm_world(self):
+        """Ranks RCCL reports for the library's communicator, or None without one."""
+        n = _lib.c_int()
+        if self._lib.bb_solver_comm_world(self._h, n) != _lib.BB_OK:
+            return None
+        return int(n.value)
+
     def peer_status(self):
         """Synchronise and raise if a peer wait ran into its time limit."""
         st = _lib.c_int()
@@ -418,6 +437,9 @@ class StructureSolver(object):
     structure_ : numpy.ndarray, shape (n_bins, 3), float64
     stress_ : numpy.ndarray, shape (n_iter,) -- stress BEFORE each step
     n_bins_, lr_ : the problem size and the step actually used
+    exchange_ : how the ranks summed their partial gradients ('rccl', 'peer', 'torch',
+        'host'), None on one rank.  Results are reproducible bit for bit for a given
+        transport; fit() never picks one by timing (that is bench.py's trial).
     """
 
     def __init__(self, n_iter=100, lr="auto", dtype="float32", alpha=3.0, kind="counts",
@@ -458,8 +480,9 @@ class StructureSolver(object):
 
     def fit(self, X, init=None):
         """Solve for the structure of `X`: a ContactMap, a square ndarray, or a
-        scipy.sparse matrix (symmetric; either triangle is enough, each pair
-        at most once) -- the sparse form never builds the dense matrix."""
+        scipy.sparse matrix (symmetric; either triangle is enough; of several
+        COO entries for one pair the last is kept) -- the sparse form never builds
+        the dense matrix."""
         matrix = getattr(X, "matrix", X)
         sparse = hasattr(matrix, "tocoo")          # any scipy.sparse matrix
         if sparse:
@@ -518,6 +541,7 @@ class StructureSolver(object):
                         break
             if getattr(eng, "_comm_state", None) == "peer":
                 eng.peer_status()              # raises if a peer wait ran into its time limit
+            self.exchange_ = getattr(eng, "_comm_state", None)
             self.structure_ = eng.get_coords()
             self.stress_ = eng.stress_history()
         finally:
@@ -532,7 +556,8 @@ class StructureSolver(object):
         bins are `int(pos / resolution)` (pyx:111-112), the matrix has
         `n_bins + 1` bins (pyx:97), and with KRnorm / KRexpected each count is
         balanced and O/E-normalised on the device as `ContactMap.normalize`
-        would (pyx:166-169).  Each bin pair may occur once."""
+        would (pyx:166-169).  A bin pair that occurs more than once keeps its last
+        count, as in the reference's scatter (pyx:115-116)."""
         t = numpy.nan_to_num(numpy.asarray(triples, dtype=numpy.float64))       # pyx:102
         if t.ndim != 2 or t.shape[1] != 3:
             raise ValueError("triples must have shape (n, 3)")
@@ -584,7 +609,73 @@ def spectral_init(eng, n, world, n_iter=40, seed=0):
     return (V @ evecs[:, order]) * numpy.sqrt(numpy.maximum(evals[order], 0.0))
 
 
-def select_exchange(eng, lr, trial=True):
+def _all_ranks(ok):
+    """Collective AND over the ranks of one local outcome: every rank learns whether
+    ALL of them succeeded, so that all of them take the same next step."""
+    import torch.distributed as dist
+    flags = [None] * dist.get_world_size()
+    dist.all_gather_object(flags, bool(ok))
+    return all(flags)
+
+
+_TRIAL_PEER_TIMEOUT_MS = 2000
+_TRIAL_SYNC_TIMEOUT_MS = int(os.environ.get("BB_TRIAL_SYNC_TIMEOUT_MS", "30000"))
+
+
+def _trial_leg(eng, name, step, lr, x0, iters):
+    """One transport's trial run from the start x0: one step (coordinates kept for the
+    agreement check), three more to warm up, `iters` timed.  After EVERY stage the ranks
+    agree on whether all of them got through it; the first stage that failed anywhere
+    ends the leg on every rank, so nobody enters a collective that a peer has left.
+    Returns (ok, coordinates after one step, seconds per iteration)."""
+    import time
+    import torch.distributed as dist
+    box = {}
+
+    def stage(fn):
+        try:
+            fn()
+            ok = True
+        except Exception as exc:                 # this transport is just not used
+            eng._comm_trial_error = "%s: %s" % (name, exc)
+            ok = False
+        return _all_ranks(ok)
+
+    def settle():
+        # bounded: a collective that a peer never joined must end the leg, not the job
+        bounded = getattr(eng, "sync_timeout", None)
+        if bounded:
+            bounded(_TRIAL_SYNC_TIMEOUT_MS)
+        else:
+            eng.sync()
+        if name == "peer":
+            eng.peer_status()                    # raises when a wait ran into its limit
+
+    def first():
+        eng.set_coords(x0)
+        step(1, lr)
+        settle()
+        box["x1"] = eng.get_coords()
+
+    def warm():
+        step(3, lr)
+        settle()
+
+    def timed():
+        t0 = time.perf_counter()
+        step(iters, lr)
+        settle()
+        box["dt"] = (time.perf_counter() - t0) / iters
+
+    for k, fn in enumerate((first, warm, timed)):
+        if k == 2:
+            dist.barrier()
+        if not stage(fn):
+            return False, None, float("inf")
+    return True, box["x1"], box["dt"]
+
+
+def select_exchange(eng, lr, trial=False):
     """Decide, once per engine and identically on every rank, how the partial
     gradients are summed over the ranks.  Collective.
 
@@ -593,18 +684,22 @@ def select_exchange(eng, lr, trial=True):
       rccl   the library's own RCCL communicator, all-reduce enqueued from C
       torch  torch.distributed all-reduce on a tensor aliasing the exchange buffer
       host   exchange buffer staged through host memory (gloo / CPU rehearsals)
-    auto on an RCCL job sets up peer and rccl, and -- when `trial` is true and the
-    coordinates have just been set -- runs a few iterations through both from the
-    same start: peer is taken only if its coordinates agree with RCCL's and it is
-    faster on the slowest rank; the start is restored afterwards.  Without a trial
-    auto means rccl.  The outcome is kept in eng._comm_state / eng._comm_trial."""
+    auto on an RCCL job means rccl (torch if the communicator cannot be made).  With
+    `trial` true -- bench.py, or BB_COMM_TRIAL=1 -- and the coordinates just set, auto
+    also sets up peer and runs a few iterations through both from the same start:
+    peer is taken only if its coordinates agree with RCCL's and it is faster on the
+    slowest rank; the start is restored afterwards.  Every stage of the trial ends
+    with an agreement between the ranks (`_trial_leg`), and the peer waits are cut
+    to 2 s while it runs, so a transport that fails on one rank is dropped by all of
+    them instead of leaving the others inside a collective.  The outcome is kept in
+    eng._comm_state / eng._comm_trial."""
     if getattr(eng, "_comm_state", None):
         return eng._comm_state
-    import time
     import torch.distributed as dist
     want = os.environ.get("BB_COMM", "auto")
     if want not in ("auto", "peer", "rccl", "torch", "host"):
         raise ValueError("BB_COMM must be auto, peer, rccl, torch or host, not %r" % want)
+    trial = bool(trial) or os.environ.get("BB_COMM_TRIAL") == "1"
     native = hasattr(eng, "peer_setup")
     nccl = dist.get_backend() == "nccl"
     state = None
@@ -617,51 +712,30 @@ def select_exchange(eng, lr, trial=True):
         state = "peer"
     elif want == "torch":
         state = "torch"
-    elif want == "rccl":
+    elif want == "rccl" or not trial:
         state = "rccl" if eng.comm_setup() else "torch"
     else:
         have_rccl = eng.comm_setup()
-        have_peer = bool(trial) and eng.peer_setup()
+        have_peer = eng.peer_setup()
         if have_rccl and have_peer:
             x0 = eng.get_coords()
+            set_limit = getattr(eng, "peer_set_timeout", None)
+            if set_limit:
+                set_limit(_TRIAL_PEER_TIMEOUT_MS)
             runs = {}
             for name, step in (("rccl", eng.iterate_dist), ("peer", eng.iterate_peer)):
-                eng.set_coords(x0)
-                ok, x1, dt = True, None, float("inf")
-
-                def attempt(fn):
-                    # a transport that fails here is just not used; the collectives
-                    # between the attempts are still entered by every rank
+                runs[name] = _trial_leg(eng, name, step, lr, x0, 10)
+                if name == "rccl" and not runs[name][0] and hasattr(eng, "comm_abort"):
+                    # the library's communicator is suspect (this rank may still sit in a
+                    # collective a peer never joined): abort it -- every rank does,
+                    # the leg's outcome is shared -- so that the stream drains again
                     try:
-                        return fn()
+                        eng.comm_abort()
                     except Exception as exc:
-                        eng._comm_trial_error = "%s: %s" % (name, exc)
-                        return None
-
-                def warm():
-                    step(1, lr)
-                    x = eng.get_coords()
-                    step(3, lr)
-                    eng.sync()
-                    return x
-
-                def timed():
-                    t0 = time.perf_counter()
-                    step(10, lr)
-                    eng.sync()
-                    t = (time.perf_counter() - t0) / 10
-                    if name == "peer":
-                        eng.peer_status()
-                    return t
-
-                x1 = attempt(warm)
-                dist.barrier()
-                t = attempt(timed) if x1 is not None else None
-                if x1 is None or t is None:
-                    ok, x1 = False, None
-                else:
-                    dt = t
-                runs[name] = (ok, x1, dt)
+                        eng._comm_trial_error = "%s; abort: %s" % (
+                            getattr(eng, "_comm_trial_error", None), exc)
+            if set_limit and runs["peer"][0]:
+                set_limit(int(os.environ.get("BB_PEER_TIMEOUT_MS", "10000")))
             eng.set_coords(x0)
             agree = bool(runs["rccl"][0] and runs["peer"][0] and numpy.allclose(
                 runs["rccl"][1], runs["peer"][1], rtol=1e-4,
@@ -676,7 +750,12 @@ def select_exchange(eng, lr, trial=True):
             eng._comm_trial = {"agree": all(e[0] for e in every), "rccl_ms": ms(t_rccl),
                                "peer_ms": ms(t_peer),
                                "error": getattr(eng, "_comm_trial_error", None)}
-            state = "peer" if use_peer else "rccl"
+            if use_peer:
+                state = "peer"
+            elif runs["rccl"][0]:
+                state = "rccl"
+            else:
+                state = "torch"
         elif have_rccl:
             state = "rccl"
         else:
@@ -695,7 +774,7 @@ def run_iterations(eng, n_iter, lr, world):
     if world == 1:
         eng.iterate(n_iter, lr)
         return
-    state = select_exchange(eng, lr, trial=False)
+    state = select_exchange(eng, lr)
     if state == "peer":
         eng.iterate_peer(n_iter, lr)
     elif state == "rccl":

@@ -128,8 +128,9 @@ BB_API int bb_solver_layout(const bb_solver *s, bb_layout_info *info, int64_t *u
 BB_API int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld, int kind,
                                     double alpha);
 /* Blocked-sparse input: nnz entries (rows[k], cols[k], vals[k]) of the symmetric
- * matrix, either triangle, each unordered pair at most once (if a pair occurs
- * twice it is unspecified which value is kept).  Every entry must fall in a
+ * matrix, either triangle; an unordered pair that occurs more than once keeps its
+ * LAST entry, as in the reference's scatter loop (blueberry/datatypes.pyx:110-116)
+ * and in bb_contactmap_scatter.  Every entry must fall in a
  * tile of the solver's tile list; all other pairs carry no constraint.  This
  * is the form of the reference's own input files -- sparse (pos_i, pos_j,
  * count) triples (blueberry/datatypes.pyx:31-38, :100-102) -- without the
@@ -183,6 +184,13 @@ BB_API int bb_comm_unique_id(void *id_out_128_bytes);
 BB_API int bb_solver_comm_init(bb_solver *s, const void *unique_id_128_bytes);
 BB_API int bb_solver_allreduce(bb_solver *s);
 BB_API int bb_solver_iterate_dist(bb_solver *s, int64_t iters, double lr);
+/* Number of ranks RCCL reports for the library's communicator (ncclCommCount): what the
+ * bench line quotes as the world size that really took part in the collective. */
+BB_API int bb_solver_comm_world(const bb_solver *s, int *world);
+/* Give the communicator up (ncclCommAbort): ends a collective that a peer never
+ * joined, so the solver's stream drains again.  The solver falls back to
+ * bb_solver_grad / caller's all-reduce / bb_solver_apply. */
+BB_API int bb_solver_comm_abort(bb_solver *s);
 
 /* Peer exchange: a one-shot all-reduce over xGMI written into the solver's own
  * kernels -- no collective library in the loop.  Every rank owns a receive
@@ -197,8 +205,13 @@ BB_API int bb_solver_iterate_dist(bb_solver *s, int64_t iters, double lr);
  *                           collective: every rank must have exported)
  *   bb_solver_iterate_peer  `iters` x { grad, reduce+push, wait+sum+apply }
  *   bb_solver_peer_status   0 = healthy; 1 = a wait ran into the time limit
- *                           (BB_PEER_TIMEOUT_MS, default 10000): later launches
- *                           skip their update and this call reports BB_ERR_STATE
+ *                           (BB_PEER_TIMEOUT_MS, default 10000) or a peer reported
+ *                           its own failure: this call reports BB_ERR_STATE
+ *   bb_solver_peer_set_timeout  change that limit (a short one for a trial run)
+ * A failure is decided ONCE per iteration, by one wave, for the whole update: X is
+ * advanced by a complete step or not at all.  The failed rank stops pushing and
+ * leaves a poison flag on every peer, so their next wait fails at once as well --
+ * no rank goes on consuming partials of coordinates that no longer move.
  * The handles travel by whatever the caller has (MPI_Allgather, torch.distributed,
  * a file).  All ranks must be on one node with peer access between their GPUs. */
 #define BB_PEER_HANDLE_BYTES 128
@@ -206,6 +219,7 @@ BB_API int bb_solver_peer_export(bb_solver *s, void *handle_out);
 BB_API int bb_solver_peer_connect(bb_solver *s, const void *handles_rank_order);
 BB_API int bb_solver_iterate_peer(bb_solver *s, int64_t iters, double lr);
 BB_API int bb_solver_peer_status(bb_solver *s, int *status);
+BB_API int bb_solver_peer_set_timeout(bb_solver *s, int64_t milliseconds);
 
 /* Host-staged access to the exchange buffer, widened to float64, for callers
  * whose collective runs on host memory (MPI, gloo): read after bb_solver_grad,
@@ -228,6 +242,9 @@ BB_API int bb_solver_stress(bb_solver *s, double *stress);
  * last bb_solver_set_coords) to the host; synchronises the stream. */
 BB_API int bb_solver_get_stress_history(bb_solver *s, double *out, int64_t cap, int64_t *n);
 BB_API int bb_solver_sync(bb_solver *s);
+/* The same with a bound: BB_ERR_STATE if the stream has not drained after
+ * `milliseconds` (polls hipStreamQuery; the work stays enqueued). */
+BB_API int bb_solver_sync_timeout(bb_solver *s, int64_t milliseconds);
 
 /* HIP-event timing of the dominant kernel (stress+gradient) and of the
  * reduce/update kernel on the solver's stream.  Averages are over the timed

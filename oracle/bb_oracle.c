@@ -126,8 +126,10 @@ BBO_API void bbo_benjamini_hochberg(const double *p_values, long d, long n, doub
     double prev_q_value = 0.0;
     for (long i = 0; i < d; i++) {
         double q_value = p_values[i] * (double)n / (double)(i + 1);
-        q_value = q_value < 1.0 ? q_value : 1.0;
-        q_value = q_value > prev_q_value ? q_value : prev_q_value;
+        /* Cython's min(q, 1) and max(q, prev) (pyx:67-68) compare this way round: a NaN
+         * p-value gives q = NaN and restarts the running maximum (golden bh_*_4..7) */
+        q_value = 1.0 < q_value ? 1.0 : q_value;
+        q_value = prev_q_value > q_value ? prev_q_value : q_value;
         q_values[i] = q_value;
         prev_q_value = q_value;
     }

@@ -90,3 +90,72 @@ class OracleEngine(object):
         a = numpy.where(own, self.w * self.w, 0.0)
         x = numpy.asarray(x, dtype=numpy.float64)
         return a @ x + a.T @ x
+
+
+class ScriptedRankEngine(object):
+    """One rank of a multi-rank job with no compute at all: what select_exchange's
+    trial sees of an engine, with the "RCCL" transport played by an ASYNC all-reduce on
+    a process group of its own (enqueue returns at once, like ncclAllReduce; the wait
+    happens in sync / sync_timeout) and the peer transport by nothing.  `fail_leg` makes
+    this rank raise at the start of that transport's first step, before it has joined
+    the collective."""
+
+    def __init__(self, rank, world, data_group, fail_leg=None):
+        self.rank, self.world, self.group, self.fail_leg = rank, world, data_group, fail_leg
+        self.x = numpy.arange(12.0).reshape(4, 3)
+        self.pending = []
+        self.aborted = False
+        self._comm_state = self._comm_trial = None
+        self._peer_error = ""
+        self.peer_failed = False
+
+    def comm_setup(self):
+        return True
+
+    def peer_setup(self):
+        return True
+
+    def peer_set_timeout(self, ms):
+        pass
+
+    def get_coords(self):
+        return self.x.copy()
+
+    def set_coords(self, x):
+        self.sync()
+        self.x = numpy.array(x, dtype=float)
+
+    def iterate_dist(self, k, lr):
+        import torch
+        import torch.distributed as dist
+        if self.fail_leg == "rccl":
+            raise RuntimeError("scripted: rccl leg fails on this rank before the collective")
+        for _ in range(k):
+            t = torch.ones(4)
+            self.pending.append(dist.all_reduce(t, group=self.group, async_op=True))
+            self.x = self.x - lr
+
+    def iterate_peer(self, k, lr):
+        if self.fail_leg == "peer":
+            self.peer_failed = True
+            return
+        self.x = self.x - lr * k
+
+    def peer_status(self):
+        if self.peer_failed:
+            raise RuntimeError("scripted: peer leg: time limit")
+        return 0
+
+    def sync(self):
+        self.sync_timeout(60000)
+
+    def sync_timeout(self, ms):
+        import datetime
+        work, self.pending = self.pending, []
+        for w in work:
+            if not w.wait(timeout=datetime.timedelta(milliseconds=ms)):
+                raise RuntimeError("scripted: stream did not drain")
+
+    def comm_abort(self):
+        self.pending = []
+        self.aborted = True

@@ -20,6 +20,7 @@ Functions captured (reference file:line):
   downsample              blueberry/blueberry.pyx:93-104
   ContactMap.__init__     blueberry/datatypes.pyx:88-120
   ContactMap.normalize    blueberry/datatypes.pyx:143-171
+  ContactMap.filter       blueberry/datatypes.pyx:122-141
   FithicContactMap        blueberry/datatypes.pyx:274-388 (__init__, contacts, to_matrix)
 """
 import os
@@ -92,6 +93,18 @@ def make_bh_downsample(bb):
         out["bh_p_%d" % k] = p
         out["bh_n_%d" % k] = numpy.int64(n)
         out["bh_q_%d" % k] = bb.benjamini_hochberg(p, n)
+    # NaN p-values (round 2; own generator, the cases above keep their bits): Cython's
+    # min(q, 1) / max(q, prev) are `1 < q ? 1 : q` and `prev > q ? prev : q`
+    # (pyx:67-68), so a NaN comes out as NaN AND restarts the running maximum
+    rng_nan = numpy.random.default_rng(12)
+    for k, (d, n, where) in enumerate(((6, 10, (2,)), (40, 100, (0, 17, 18)), (2500, 9000, (1023, 1024, 2047)),
+                                       (5, 5, (4,))), start=4):
+        p = numpy.sort(rng_nan.random(d) ** 3)
+        p[list(where)] = numpy.nan
+        out["bh_p_%d" % k] = p
+        out["bh_n_%d" % k] = numpy.int64(n)
+        with numpy.errstate(all="ignore"):
+            out["bh_q_%d" % k] = bb.benjamini_hochberg(p, n)
     for k, n5 in enumerate((2, 7, 20)):
         yp1 = rng.random((n5 * 5, n5 * 5)).astype(numpy.float32)
         yp5i = (rng.random((n5, n5)) * 0.9).astype(numpy.float32)
@@ -136,6 +149,21 @@ def make_contactmap(dt, tmp):
         with numpy.errstate(all="ignore"):
             cm.normalize()
         out["cm%d_matrix_norm" % k] = cm.matrix.copy()
+        # A4 (round 2): the real ContactMap.filter (pyx:122-141) on the raw and on the
+        # normalised map, threshold 0 and the median marginal; n_bins / regions are
+        # stored as the reference leaves them (stale)
+        for tagf, do_norm, med in (("raw_t0", False, False), ("raw_tmed", False, True),
+                                   ("norm_t0", True, False), ("norm_tmed", True, True)):
+            cf = dt.ContactMap("cell%d" % k, k + 1, res)
+            if do_norm:
+                with numpy.errstate(all="ignore"):
+                    cf.normalize()
+            thr = float(numpy.median(cf.matrix.sum(axis=0))) if med else 0.0
+            cf.filter(thr)
+            out["cm%d_filter_%s_thr" % (k, tagf)] = numpy.float64(thr)
+            out["cm%d_filter_%s_matrix" % (k, tagf)] = numpy.ascontiguousarray(cf.matrix)
+            out["cm%d_filter_%s_n_bins" % (k, tagf)] = numpy.int64(cf.n_bins)
+            out["cm%d_filter_%s_regions" % (k, tagf)] = cf.regions.copy()
     # A zero KR entry: Cython's default cdivision=False turns the C division
     # at datatypes.pyx:168 into a checked one, so the reference raises.
     numpy.savetxt(dt.KR_NORM.format("cell0", 1, 50.0), numpy.array([1.0, 0.0, 1.0, 1.0, 1.0, 1.0]))

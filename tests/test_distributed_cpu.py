@@ -165,13 +165,82 @@ def test_select_exchange_auto_is_a_measured_validated_choice(one_rank_group, mon
     monkeypatch.setattr(one_rank_group, "get_backend", lambda *a, **k: "nccl")
     e = _ScriptedEngine(**kwargs)
     x0 = e.get_coords()
-    assert solver.select_exchange(e, 0.5) == expect
+    assert solver.select_exchange(e, 0.5, trial=True) == expect
     assert e._comm_state == expect
     assert numpy.array_equal(e.get_coords(), x0)               # the start is restored
     if kwargs.get("peer_ok", True) and kwargs.get("rccl_ok", True):
         agree = not kwargs.get("peer_shift") and not kwargs.get("peer_raises")
         assert e._comm_trial["agree"] == agree
     assert solver.select_exchange(e, 0.5) == expect            # decided once
+
+
+def test_select_exchange_without_trial_is_rccl(one_rank_group, monkeypatch):
+    """fit() never picks a transport by timing: auto = the library's RCCL communicator,
+    torch.distributed if that cannot be made; BB_COMM_TRIAL=1 opts in to the trial."""
+    from blueberry_amd import solver
+    monkeypatch.setattr(one_rank_group, "get_backend", lambda *a, **k: "nccl")
+    e = _ScriptedEngine(peer_sleep=0.0, rccl_sleep=0.002)
+    assert solver.select_exchange(e, 0.5) == "rccl" and e.calls == []
+    assert solver.select_exchange(_ScriptedEngine(rccl_ok=False), 0.5) == "torch"
+    monkeypatch.setenv("BB_COMM_TRIAL", "1")
+    assert solver.select_exchange(_ScriptedEngine(rccl_sleep=0.002), 0.5) == "peer"
+
+
+def _trial_worker(rank, world, port, fail_rank, fail_leg, q):
+    """One rank of a world-2 trial whose `fail_rank` raises at the start of `fail_leg`,
+    BEFORE it joins that transport's collective -- the other rank is already inside."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["BB_TRIAL_SYNC_TIMEOUT_MS"] = "1500"
+        os.environ.pop("BB_COMM", None)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        data = dist.new_group(backend="gloo")        # the transport's own communicator
+        dist.get_backend = lambda *a, **k: "nccl"    # take select_exchange's RCCL branch
+        from blueberry_amd import solver
+        from tests._engines import ScriptedRankEngine
+        e = ScriptedRankEngine(rank, world, data,
+                               fail_leg=fail_leg if rank == fail_rank else None)
+        x0 = e.get_coords()
+        state = solver.select_exchange(e, 0.5, trial=True)
+        q.put((rank, state, e._comm_trial, e.aborted, bool(numpy.array_equal(e.get_coords(), x0))))
+    except Exception:
+        q.put((rank, "FAILED " + traceback.format_exc(), None, None, None))
+    q.close()
+    q.join_thread()      # the result must have left before the hard exit
+    os._exit(0)          # a collective nobody will ever complete may still be pending
+
+
+@pytest.mark.parametrize("fail_leg,expect,aborted", [("rccl", "torch", True),
+                                                     ("peer", "rccl", False),
+                                                     (None, "peer", False)])
+def test_trial_with_a_rank_that_fails_before_its_collective(fail_leg, expect, aborted):
+    """a rank whose warm-up raised used to skip the timed collective
+    while the others entered it.  Now every stage ends with an agreement, waits on the
+    device are bounded, and a communicator with a collective in flight is aborted: both
+    ranks come out with the SAME transport, and nobody hangs."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trial_worker, args=(r, 2, port, 1, fail_leg, q))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=30)
+    for r in results:
+        assert not r[1].startswith("FAILED"), r[1]
+    assert [r[1] for r in results] == [expect, expect]
+    for rank, state, trial, was_aborted, restored in results:
+        assert restored
+        assert was_aborted == aborted
+        assert trial["agree"] == (fail_leg is None)
+        if fail_leg and rank == 1:                 # the rank that failed says why
+            assert fail_leg in trial["error"]
 
 
 def test_select_exchange_overrides(one_rank_group, monkeypatch):

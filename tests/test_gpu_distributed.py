@@ -149,7 +149,7 @@ def test_peer_exchange_in_one_process(dtype, tol, world, monkeypatch):
 
 def test_peer_exchange_times_out_cleanly(monkeypatch):
     """A rank whose peer never delivers must not hang: the wait is bounded, the
-    update is skipped, the failure is sticky and reported."""
+    update is skipped as a whole, the failure is sticky and reported."""
     monkeypatch.setenv("BB_PEER_TIMEOUT_MS", "200")
     from tests import _oracle
     n = 600
@@ -160,6 +160,42 @@ def test_peer_exchange_times_out_cleanly(monkeypatch):
     with pytest.raises(RuntimeError, match="time limit"):
         engs[0].peer_status()
     assert numpy.array_equal(engs[0].get_coords(), x0.astype(numpy.float32).astype(numpy.float64))
+    for e in engs:
+        e.close()
+
+
+def test_stalled_rank_fails_every_rank_and_leaves_x_whole(monkeypatch):
+    """with every workgroup of the update polling for itself, a
+    time-out could apply a step to part of X, and the timed-out rank kept feeding its
+    peers partials of coordinates that no longer moved.  Now one wave decides per
+    launch, and a failed rank poisons its flag on every peer.  Three ranks, rank 2
+    stalled for good: rank 0 (200 ms limit) times out; rank 1 (60 s limit) must fail
+    right behind it -- through the poison, not through its own clock -- and on both X
+    is exactly the start, on every element."""
+    import time
+    monkeypatch.setenv("BB_PEER_TIMEOUT_MS", "60000")
+    from tests import _oracle
+    n = 5000                                       # 30 workgroups in the update launch
+    xs = _oracle.random_walk(n)
+    x0 = _oracle.noisy_init(xs)
+    engs = _peer_engines(3, n, "float32", _oracle.wish_from_coords(xs), x0)
+    engs[0].peer_set_timeout(200)
+    t0 = time.perf_counter()
+    for e in engs[:2]:
+        e.iterate_peer(4, 1.0 / (2 * n))           # rank 2 never runs
+    for e in engs[:2]:
+        with pytest.raises(RuntimeError, match="time limit"):
+            e.peer_status()
+    assert time.perf_counter() - t0 < 20.0         # nobody sat out a 60 s limit
+    want = x0.astype(numpy.float32).astype(numpy.float64)
+    for e in engs[:2]:
+        assert numpy.array_equal(e.get_coords(), want)
+        assert e.stress_history().size == 4        # the slots exist; none was applied
+    # the stalled rank, once it does run, finds the poison and stops as well
+    engs[2].iterate_peer(1, 1.0 / (2 * n))
+    with pytest.raises(RuntimeError, match="time limit"):
+        engs[2].peer_status()
+    assert numpy.array_equal(engs[2].get_coords(), want)
     for e in engs:
         e.close()
 

@@ -481,12 +481,44 @@ def test_fit_triples_equals_contactmap_pipeline(oracle):
         bb.StructureSolver(n_iter=1).fit_triples(triples, res, n_bins, KRnorm=kr0, KRexpected=ke)
 
 
+def test_fit_triples_repeated_pairs_last_entry_wins(oracle):
+    """a bin pair that occurs several times in the triples -- in
+    either orientation -- keeps its LAST count on the triples path exactly as on the
+    ContactMap path (reference scatter, datatypes.pyx:110-116: later rows overwrite)."""
+    rng = numpy.random.default_rng(21)
+    n_bins, res, k = 600, 5000, 4
+    m = 30000
+    bi = rng.integers(0, n_bins, m)
+    bj = numpy.minimum(n_bins - 1, bi + rng.geometric(0.05, m))      # many repeats
+    flip = rng.random(m) < 0.5                                       # (j, i) as well as (i, j)
+    bi, bj = numpy.where(flip, bj, bi), numpy.where(flip, bi, bj)
+    counts = rng.integers(1, 900, m).astype(float)
+    lo, hi = numpy.minimum(bi, bj), numpy.maximum(bi, bj)
+    assert numpy.unique(lo * n_bins + hi).size < 0.8 * m             # repeats are the point
+    triples = numpy.stack([bi * float(res), bj * float(res), counts], 1)
+    n = n_bins + 1
+    x0 = numpy.random.default_rng(2).standard_normal((n, 3))
+    lr = 1.0 / (2 * n)
+    raw = oracle.contactmap_scatter(triples, res, n_bins)
+    X_ref, h_ref = oracle.solve(oracle.counts_to_wish(raw, 3.0), x0, k, lr)
+    cm = bb.ContactMap.from_matrix(bb.datatypes.scatter_triples(triples, res, n_bins), resolution=res)
+    assert numpy.array_equal(cm.matrix, raw)
+    for dtype, tol in (("float64", 1e-12), ("float32", 1e-5)):
+        dense = bb.StructureSolver(n_iter=k, lr=lr, dtype=dtype).fit(cm, init=x0)
+        direct = bb.StructureSolver(n_iter=k, lr=lr, dtype=dtype).fit_triples(
+            triples, res, n_bins, init=x0)
+        assert numpy.array_equal(dense.stress_, direct.stress_), dtype     # the same units
+        assert numpy.array_equal(dense.structure_, direct.structure_), dtype
+        assert numpy.abs(direct.stress_ / h_ref - 1).max() < tol, dtype
+        assert _rel(direct.structure_, X_ref) < tol, dtype
+
+
 # ---- the two remaining numeric helpers of blueberry.pyx ---------------------------
-@pytest.mark.parametrize("k", [0, 1, 2, 3])
+@pytest.mark.parametrize("k", range(8))         # 4..7: NaN p-values (NaN out, maximum restarts)
 def test_bh_golden_bit_exact(k):
     z = _oracle.golden("bh_downsample")
     q = bb.benjamini_hochberg(z["bh_p_%d" % k], int(z["bh_n_%d" % k]))
-    assert numpy.array_equal(q, z["bh_q_%d" % k])
+    assert numpy.array_equal(q, z["bh_q_%d" % k], equal_nan=True)
 
 
 @pytest.mark.parametrize("d", [1, 255, 1024, 1025, 300000, 2000003])
@@ -496,6 +528,13 @@ def test_bh_vs_oracle_ragged(oracle, d):
     n = int(d * 3.7) + 5
     assert numpy.array_equal(bb.benjamini_hochberg(p, n), oracle.benjamini_hochberg(p, n))
     assert bb.benjamini_hochberg(numpy.zeros(0), 10).shape == (0,)
+    # NaNs anywhere -- first and last element, runs, workgroup (1024) boundaries
+    p[rng.integers(0, d, size=max(1, d // 300))] = numpy.nan
+    for i in (0, d - 1, 1023, 1024, 1025, 2047):
+        if i < d:
+            p[i] = numpy.nan
+    assert numpy.array_equal(bb.benjamini_hochberg(p, n), oracle.benjamini_hochberg(p, n),
+                             equal_nan=True)
 
 
 @pytest.mark.parametrize("k", [0, 1, 2])

@@ -50,11 +50,13 @@ def test_reference_raises_on_zero_kr():
 
 
 # ---- f4: benjamini_hochberg / downsample (blueberry.pyx:40-75, 93-104) -----
-@pytest.mark.parametrize("k", [0, 1, 2, 3])
+@pytest.mark.parametrize("k", range(8))         # 4..7: NaN p-values (NaN out, maximum restarts)
 def test_bh_matches_reference(oracle, k):
     z = _oracle.golden("bh_downsample")
     q = oracle.benjamini_hochberg(z["bh_p_%d" % k], int(z["bh_n_%d" % k]))
-    assert numpy.array_equal(q, z["bh_q_%d" % k])
+    assert numpy.array_equal(q, z["bh_q_%d" % k], equal_nan=True)
+    if k >= 4:
+        assert numpy.isnan(z["bh_q_%d" % k]).sum() == numpy.isnan(z["bh_p_%d" % k]).sum() > 0
 
 
 @pytest.mark.parametrize("k", [0, 1, 2])
@@ -189,3 +191,36 @@ def test_multicore_baseline_equals_scalar_oracle(oracle, threads):
     assert numpy.abs(ht / h1 - 1).max() < 1e-12
     Xt2, ht2 = _oracle.solve_mt(w, x0, 6, 1.0 / (2 * n), threads)
     assert numpy.array_equal(Xt, Xt2) and numpy.array_equal(ht, ht2)   # reproducible
+
+
+def test_solver_oracle_equals_sklearn_smacof_on_a_complete_map(oracle):
+    """S0 has no reference to pin to, so the oracle's solver is
+    additionally pinned to a NAMED third-party algorithm: for a complete wish matrix, one
+    step of `bbo_solve` with lr = 1/(2N) is the Guttman transform, i.e. one iteration
+    of scikit-learn's metric SMACOF (`sklearn.manifold.smacof`, `_smacof_single`:
+    X <- B(X) X / n, then the raw stress of the NEW X).  K chained single iterations
+    of sklearn from the oracle's own iterates must give the oracle's stress history
+    (shifted by one: sklearn reports S(X_{k+1})) and its coordinates up to the centroid
+    -- the Guttman transform centres X, the gradient step keeps X's centroid.
+    Tolerances: sklearn's euclidean_distances uses the |x|^2 + |y|^2 - 2xy expansion
+    (about 1e-12 relative on these distances), so 1e-9, not 1e-12.  Incomplete maps
+    (weights) have no sklearn counterpart and stay pinned by closed forms only."""
+    smacof = pytest.importorskip("sklearn.manifold").smacof
+    n, k = 60, 6
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    x0 = _oracle.noisy_init(xs)
+    lr = 1.0 / (2 * n)
+    X, hist, iterates = x0.copy(), [], [x0.copy()]
+    for _ in range(k + 1):
+        X, h = oracle.solve(w, X, 1, lr)          # one step at a time: keep every iterate
+        hist.append(h[0])
+        iterates.append(X.copy())
+    X_all, h_all = oracle.solve(w, x0, k + 1, lr)
+    assert numpy.array_equal(h_all, numpy.array(hist))          # chaining changes nothing
+    for it in range(k):
+        Xs, stress, _ = smacof(w, metric=True, n_components=3, init=iterates[it], n_init=1,
+                               max_iter=1, eps=0.0, normalized_stress=False, return_n_iter=True)
+        assert abs(stress / hist[it + 1] - 1) < 1e-9, (it, stress, hist[it + 1])
+        mine = iterates[it + 1] - iterates[it + 1].mean(axis=0)
+        assert numpy.abs(Xs - mine).max() < 1e-9 * numpy.abs(mine).max(), it
