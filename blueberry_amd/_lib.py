@@ -82,6 +82,17 @@ SIGNATURES = {
     "bb_solver_get_step_timing": (c_int, [c_void_p, p_dbl]),
     "bb_solver_measure_stream_read": (c_int, [c_void_p, c_int, p_dbl]),
     "bb_solver_traffic": (c_int, [c_void_p, p_i64, p_i64]),
+    "bb_cm_create": (c_int, [ctypes.POINTER(c_void_p), c_i64, c_int]),
+    "bb_cm_destroy": (c_int, [c_void_p]),
+    "bb_cm_dim": (c_int, [c_void_p, p_i64]),
+    "bb_cm_device_ptr": (c_int, [c_void_p, ctypes.POINTER(c_void_p), p_i64, ctypes.POINTER(c_int)]),
+    "bb_cm_upload": (c_int, [c_void_p, p_dbl, c_i64]),
+    "bb_cm_download": (c_int, [c_void_p, p_dbl, c_i64]),
+    "bb_cm_scatter": (c_int, [c_void_p, p_dbl, c_i64, c_i32]),
+    "bb_cm_normalize": (c_int, [c_void_p, c_i64, p_dbl, p_dbl]),
+    "bb_cm_marginals": (c_int, [c_void_p, p_dbl]),
+    "bb_cm_filter": (c_int, [c_void_p, c_dbl, p_i64, ctypes.POINTER(ctypes.c_uint8)]),
+    "bb_solver_set_wish_from_cm": (c_int, [c_void_p, c_void_p, c_int, c_dbl]),
     "bb_contactmap_scatter": (c_int, [p_dbl, c_i64, c_i32, p_dbl, c_i64, c_int]),
     "bb_contactmap_normalize": (c_int, [p_dbl, c_i64, p_dbl, p_dbl, c_int]),
     "bb_benjamini_hochberg": (c_int, [p_dbl, c_i64, c_i64, p_dbl, c_int]),

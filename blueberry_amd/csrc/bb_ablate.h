@@ -1,7 +1,7 @@
 // bb_ablate.h -- timing-only ablation switches of the solver kernels.  NEVER defined in
 // the product build (build.sh): each BB_ABL_* macro removes one part of
 // stress_grad_kernel so that tools/tools_abl.sh can price it (the results are wrong by
-// design).  The kernels test the constexpr flags below, so the product source carries
+// design); BB_WAVE_TRACE keeps the results and adds five time stamps per wave.  The kernels test the constexpr flags below, so the product source carries
 // no #ifdef and the product object no trace of them.
 #pragma once
 
@@ -41,6 +41,11 @@ BB_ABL_FLAG(kXrowVector, false);
 BB_ABL_FLAG(kF64Libm, true);
 #else
 BB_ABL_FLAG(kF64Libm, false);
+#endif
+#ifdef BB_WAVE_TRACE          // diagnostic build: per-wave time stamps (tools/wave_trace.py)
+BB_ABL_FLAG(kWaveTrace, true);
+#else
+BB_ABL_FLAG(kWaveTrace, false);
 #endif
 #undef BB_ABL_FLAG
 }  // namespace abl

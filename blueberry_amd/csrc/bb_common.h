@@ -24,6 +24,12 @@ int fail(int code, const std::string &msg);
             return ::bb::fail(BB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
+#define BB_TRY(expr)                  \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != BB_OK) return _rc; \
+    } while (0)
+
 #define BB_REQUIRE(cond, msg)                                   \
     do {                                                        \
         if (!(cond)) return ::bb::fail(BB_ERR_INVALID, (msg));  \
@@ -39,6 +45,9 @@ int fail(int code, const std::string &msg);
 // N=6,000 is 64 narrow / 52 wide.
 constexpr int kUnitBytes = 8192;
 constexpr int64_t kF64WideFrom = 4096;
+// Up to this many bins a one-rank solver iterates on the row-owner path (both
+// triangles resident, one wave per bin, one launch per iteration: DESIGN.md 4.10).
+constexpr int64_t kRowOwnerMaxBins = 4096;
 
 inline int64_t elem_size(int dtype) { return dtype == BB_F64 ? 8 : 4; }
 inline bool wide_layout(int dtype, int64_t n_bins) { return dtype != BB_F64 || n_bins > kF64WideFrom; }

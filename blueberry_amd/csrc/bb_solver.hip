@@ -40,7 +40,7 @@ struct bb_solver {
     double momentum = 0.0;
     bool own_exch = false;
     int2 *d_udesc = nullptr;
-    int2 *d_wave_range = nullptr;
+    int chunk_q = 0, chunk_r = 0;  // units per wave: n_local = n_waves * q + r
     bool nontemporal = true;
     int32_t *d_wave_slot = nullptr;
     double *d_stresspart = nullptr;
@@ -72,6 +72,16 @@ struct bb_solver {
     long long peer_limit_ticks = 0;
     bool peer_connected = false;
 
+    // row-owner path (small maps, world = 1): both triangles resident, one launch per
+    // iteration (row_owner_kernel); the units stay resident too and serve every other
+    // entry point (grad / apply, stress, matvec)
+    bool row_owner = false;
+    void *d_full = nullptr, *d_X2 = nullptr;
+    int64_t full_ld = 0;
+    double *d_ro_part = nullptr;   // 2 x ro_blocks per-workgroup stress sums (ping-pong)
+    int ro_blocks = 0, ro_wpr = 1;  // workgroups holding rows; waves per row (1, 2, 4)
+    int64_t ro_launches = 0;       // row-owner launches so far (parity of the ping-pong)
+
     bool timing = false;
     int timing_stride = 1;      // events on every timing_stride-th iteration
     int64_t timing_iter = 0;    // iterations seen since timing was (re-)enabled
@@ -94,12 +104,6 @@ int dev_alloc(T **p, int64_t count) {
     return BB_OK;
 }
 
-#define BB_TRY(expr)                 \
-    do {                             \
-        int _rc = (expr);            \
-        if (_rc != BB_OK) return _rc; \
-    } while (0)
-
 // Waves per CU (4 waves = one workgroup).  Measured on MI355X: with the rolling
 // 8-KiB window one wave per SIMD already keeps enough bytes in flight, and fewer,
 // longer chunks mean fewer column-partial slots and less prologue per byte; two
@@ -115,6 +119,14 @@ int waves_per_cu(int64_t n_local) {
     if (v < 1) v = 1;
     if (v > 32) v = 32;
     return v;
+}
+
+// Largest map (bins) that iterates on the row-owner path.  Measured on MI355X
+// (tools/small_n_timing.py, profiles/r02_small_n.txt); BB_ROW_OWNER_MAX overrides,
+// 0 turns the path off.
+int64_t row_owner_max() {
+    const char *e = getenv("BB_ROW_OWNER_MAX");
+    return e ? atoll(e) : bb::kRowOwnerMaxBins;
 }
 
 // Build every index the kernels need from (tile list, unit range).
@@ -148,13 +160,16 @@ int build_indices(bb_solver *s) {
         const char *e = getenv("BB_NT");
         s->nontemporal = !(e && atoi(e) == 0);
     }
-    // wave w owns the contiguous chunk [n_local*w/nw, n_local*(w+1)/nw)
+    // wave w owns the contiguous chunk [w*q + min(w, r), +q (+1 if w < r)), q = n_local / nw,
+    // r = n_local % nw: the kernels compute it the same way (no table to load)
+    s->chunk_q = (int)(s->n_local / nw);
+    s->chunk_r = (int)(s->n_local % nw);
     std::vector<int2> wave_range(nw);
     std::vector<int32_t> wave_slot(nw);
     int64_t chunk_max = 0;
     for (int64_t w = 0; w < nw; ++w) {
-        wave_range[w] = make_int2((int)((__int128)s->n_local * w / nw),
-                                  (int)((__int128)s->n_local * (w + 1) / nw));
+        const int64_t a = w * s->chunk_q + std::min<int64_t>(w, s->chunk_r);
+        wave_range[w] = make_int2((int)a, (int)(a + s->chunk_q + (w < s->chunk_r ? 1 : 0)));
         chunk_max = std::max<int64_t>(chunk_max, wave_range[w].y - wave_range[w].x);
     }
     {
@@ -232,9 +247,8 @@ int build_indices(bb_solver *s) {
     BB_TRY(dev_alloc((char **)&s->d_V, s->L.n_pad * 3 * es));
     BB_TRY(dev_alloc((char **)&s->d_part, part_total * es));
     BB_TRY(dev_alloc(&s->d_udesc, (int64_t)s->udesc.size()));
-    BB_TRY(dev_alloc(&s->d_wave_range, nw));
     BB_TRY(dev_alloc(&s->d_wave_slot, nw));
-    BB_TRY(dev_alloc(&s->d_stresspart, nw));
+    BB_TRY(dev_alloc(&s->d_stresspart, nw * 6));   // nw partials (+ 5 stamps per wave, diagnostic build)
     BB_TRY(dev_alloc(&s->d_blk_ptr, nb + 1));
     BB_TRY(dev_alloc(&s->d_blk_chunk, (int64_t)fin_chunk.size()));
     BB_TRY(dev_alloc(&s->d_s1_ptr, (int64_t)s1_ptr.size()));
@@ -245,11 +259,22 @@ int build_indices(bb_solver *s) {
     BB_TRY(dev_alloc((char **)&s->d_exch, (3 * s->L.n_pad + 2) * es));
     s->own_exch = true;
     s->hist_cap = kHistCap;
+    if (s->row_owner) {
+        s->full_ld = bb::round_up(s->L.n_bins, kRowTrip);
+        // waves per row: enough of them that a small map still covers the chip with
+        // about 16 waves per CU (N=963: 4 per row); BB_ROW_OWNER_WPR overrides
+        const char *ew = getenv("BB_ROW_OWNER_WPR");
+        int wpr = ew ? atoi(ew) : (s->L.n_bins <= 1024 ? 4 : (s->L.n_bins <= 2048 ? 2 : 1));
+        s->ro_wpr = wpr >= 4 ? 4 : (wpr >= 2 ? 2 : 1);
+        const int rows_per_wg = 4 / s->ro_wpr;
+        s->ro_blocks = (int)((s->L.n_bins + rows_per_wg - 1) / rows_per_wg);
+        BB_TRY(dev_alloc((char **)&s->d_full, s->L.n_bins * s->full_ld * es));
+        BB_TRY(dev_alloc((char **)&s->d_X2, s->L.n_pad * 3 * es));
+        BB_TRY(dev_alloc(&s->d_ro_part, 2 * (int64_t)s->ro_blocks));
+    }
 
     hipStream_t st = s->stream;
     BB_HIP_CHECK(hipMemcpyAsync(s->d_udesc, s->udesc.data(), s->udesc.size() * sizeof(int2),
-                                hipMemcpyHostToDevice, st));
-    BB_HIP_CHECK(hipMemcpyAsync(s->d_wave_range, wave_range.data(), nw * sizeof(int2),
                                 hipMemcpyHostToDevice, st));
     BB_HIP_CHECK(hipMemcpyAsync(s->d_wave_slot, wave_slot.data(), nw * sizeof(int32_t),
                                 hipMemcpyHostToDevice, st));
@@ -265,6 +290,8 @@ int build_indices(bb_solver *s) {
     BB_HIP_CHECK(hipMemsetAsync(s->d_part, 0, (size_t)part_total * es, st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_X, 0, (size_t)(s->L.n_pad * 3 * es), st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_V, 0, (size_t)(s->L.n_pad * 3 * es), st));
+    if (s->row_owner)
+        BB_HIP_CHECK(hipMemsetAsync(s->d_X2, 0, (size_t)(s->L.n_pad * 3 * es), st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_exch, 0, (size_t)((3 * s->L.n_pad + 2) * es), st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_stresspart, 0, (size_t)nw * sizeof(double), st));
     BB_HIP_CHECK(hipStreamSynchronize(st));  // the host vectors above die with this scope
@@ -299,8 +326,8 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
             s->defer_attr_done |= bit;                                                          \
         }                                                                                       \
         BB_HIP_CHECK(bb::launch(kern, grid, block, (size_t)(LDS), s->stream, units, X,          \
-                                s->d_udesc, s->d_wave_range, s->d_wave_slot, rowpart, colpart,  \
-                                s->d_stresspart, s->defer_cap_units));                          \
+                                s->d_udesc, s->chunk_q, s->chunk_r, s->d_wave_slot, rowpart,    \
+                                colpart, s->d_stresspart, s->defer_cap_units));                 \
     } while (0)
 #define BB_LAUNCH(NTV, OPV)                                                                     \
     do {                                                                                        \
@@ -345,18 +372,19 @@ int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, doubl
         p.seq = s->peer_seq;
         p.n_peers = s->world;
     }
+    const unsigned segs = 3 * Lay<T, W>::VW / kRedWG;   // workgroups per block of 3*vw elements
     if (mode != kReduceStressOnly && s->n_slices > 0) {
         p.blk_ptr = s->d_s1_ptr;
         p.blk_chunk = s->d_s1_chunk;
         p.mode = kReducePartial;
-        BB_HIP_CHECK(bb::launch(reduce_kernel<T, W>, dim3((unsigned)s->n_slices), dim3(256), 0,
-                                s->stream, p));
+        BB_HIP_CHECK(bb::launch(reduce_kernel<T, W>, dim3((unsigned)s->n_slices, segs), dim3(kRedWG),
+                                0, s->stream, p));
     }
     p.blk_ptr = s->d_blk_ptr;
     p.blk_chunk = s->d_blk_chunk;
     p.mode = mode;
-    const int grid = mode == kReduceStressOnly ? 1 : (int)s->L.n_blocks;
-    BB_HIP_CHECK(bb::launch(reduce_kernel<T, W>, dim3(grid), dim3(256), 0, s->stream, p));
+    const dim3 grid = mode == kReduceStressOnly ? dim3(1, 1) : dim3((unsigned)s->L.n_blocks, segs);
+    BB_HIP_CHECK(bb::launch(reduce_kernel<T, W>, grid, dim3(kRedWG), 0, s->stream, p));
     return BB_OK;
 }
 
@@ -450,6 +478,56 @@ int set_wish_dense_t(bb_solver *s, const double *host, int64_t ld, int kind, dou
     return rc;
 }
 
+// Row-owner path: rebuild both triangles from the freshly packed units.
+int refresh_full(bb_solver *s) {
+    if (!s->row_owner) return BB_OK;
+    const int64_t es = bb::elem_size(s->dtype);
+    BB_HIP_CHECK(hipMemsetAsync(s->d_full, 0, (size_t)(s->L.n_bins * s->full_ld * es), s->stream));
+    if (s->n_local > 0) {
+#define BB_FULL(TT, WW)                                                                         \
+    BB_HIP_CHECK(bb::launch(units_to_full_kernel<TT, WW>, dim3((unsigned)s->n_local), dim3(256), 0, \
+                            s->stream, (const TT *)s->d_units, s->d_udesc, (TT *)s->d_full,       \
+                            s->full_ld, s->L.n_bins))
+        if (s->dtype == BB_F32) BB_FULL(float, true);
+        else if (s->wide) BB_FULL(double, true);
+        else BB_FULL(double, false);
+#undef BB_FULL
+    }
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    return BB_OK;
+}
+
+// One row-owner launch: iteration `hist_n` (reads d_X, writes d_X2, swaps them) and the
+// fold of the previous launch's stress into hist[hist_n - 1] when `fold_prev`.
+// update = false: fold only (after the last iteration of a call).
+template <typename T>
+int launch_row_owner_t(bb_solver *s, double lr, bool fold_prev, bool update) {
+    const int par = (int)(s->ro_launches & 1);
+    const double *prev = s->d_ro_part + (int64_t)(par ^ 1) * s->ro_blocks;
+    double *out = s->d_ro_part + (int64_t)par * s->ro_blocks;
+    double *hist_prev = fold_prev ? s->d_stress_hist + (s->hist_n - 1) : nullptr;
+    // fold only: a grid of one workgroup, which is then the "last" = the fold workgroup
+    const unsigned grid = update ? (unsigned)s->ro_blocks + 1u : 1u;
+#define BB_ROW(WPRV)                                                                             \
+    BB_HIP_CHECK(bb::launch(row_owner_kernel<T, WPRV>, dim3(grid), dim3(256), 0, s->stream,          \
+                            (const T *)s->d_full, s->full_ld, (int)s->L.n_bins, (const T *)s->d_X,  \
+                            (T *)s->d_X2, (T *)s->d_V, (T)lr, (T)s->momentum, prev, s->ro_blocks,   \
+                            hist_prev, out))
+    if (s->ro_wpr == 4) BB_ROW(4);
+    else if (s->ro_wpr == 2) BB_ROW(2);
+    else BB_ROW(1);
+#undef BB_ROW
+    if (update) {
+        std::swap(s->d_X, s->d_X2);
+        s->ro_launches++;
+    }
+    return BB_OK;
+}
+int launch_row_owner(bb_solver *s, double lr, bool fold_prev, bool update) {
+    return s->dtype == BB_F32 ? launch_row_owner_t<float>(s, lr, fold_prev, update)
+                              : launch_row_owner_t<double>(s, lr, fold_prev, update);
+}
+
 }  // namespace
 
 // ---- peer exchange ---------------------------------------------------------
@@ -516,6 +594,7 @@ int bb_solver_create(bb_solver **out, int64_t n_bins, int dtype, int device, int
     s->world = world;
     int rc = bb_layout_dense_info(n_bins, dtype, &s->L);
     s->wide = bb::wide_layout(dtype, n_bins);
+    s->row_owner = world == 1 && n_bins <= row_owner_max();
     if (rc == BB_OK) {
         if (tile_I == nullptr) {
             s->tile_I.resize((size_t)s->L.n_tiles);
@@ -577,7 +656,6 @@ int bb_solver_destroy(bb_solver *s) {
     hipFree(s->d_part);
     if (s->own_exch) hipFree(s->d_exch);
     hipFree(s->d_udesc);
-    hipFree(s->d_wave_range);
     hipFree(s->d_wave_slot);
     hipFree(s->d_stresspart);
     hipFree(s->d_blk_ptr);
@@ -587,6 +665,9 @@ int bb_solver_destroy(bb_solver *s) {
     hipFree(s->d_stress_hist);
     hipFree(s->d_stress_scalar);
     hipFree(s->d_f64_tmp);
+    hipFree(s->d_full);
+    hipFree(s->d_X2);
+    hipFree(s->d_ro_part);
     if (s->own_stream && s->stream) hipStreamDestroy(s->stream);
     delete s;
     // tear-down is best effort (a free can fail when a peer process has already gone
@@ -622,8 +703,39 @@ int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld, int k
     BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_dense: alpha must be > 0");
     BB_TRY(bb::enter_device(s->device));
     int rc = BB_BY_LAYOUT(s, set_wish_dense_t, s, host, ld, kind, alpha);
+    if (rc == BB_OK) rc = refresh_full(s);
     if (rc == BB_OK) s->have_wish = true;
     return rc;
+}
+
+int bb_solver_set_wish_from_cm(bb_solver *s, const bb_cm *cm, int kind, double alpha) {
+    BB_REQUIRE(s != nullptr && cm != nullptr, "bb_solver_set_wish_from_cm: NULL argument");
+    BB_REQUIRE(kind == BB_KIND_WISH || kind == BB_KIND_COUNTS,
+               "bb_solver_set_wish_from_cm: bad kind");
+    BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_from_cm: alpha must be > 0");
+    const double *m = nullptr;
+    int64_t d = 0;
+    int dev = -1;
+    BB_TRY(bb_cm_device_ptr(cm, &m, &d, &dev));
+    BB_REQUIRE(d == s->L.n_bins,
+               "bb_solver_set_wish_from_cm: the map's edge differs from the solver's n_bins");
+    BB_REQUIRE(dev == s->device,
+               "bb_solver_set_wish_from_cm: the map lives on another device than the solver");
+    BB_TRY(bb::enter_device(s->device));
+    if (s->n_local > 0) {
+#define BB_PACK(TT, WW)                                                                          \
+    BB_HIP_CHECK(bb::launch(pack_units_from_matrix_kernel<TT, WW>, dim3((unsigned)s->n_local),       \
+                            dim3(256), 0, s->stream, m, d, (TT *)s->d_units, s->d_udesc,          \
+                            s->L.n_bins, kind, -1.0 / alpha))
+        if (s->dtype == BB_F32) BB_PACK(float, true);
+        else if (s->wide) BB_PACK(double, true);
+        else BB_PACK(double, false);
+#undef BB_PACK
+    }
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    BB_TRY(refresh_full(s));
+    s->have_wish = true;
+    return BB_OK;
 }
 
 int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *cols,
@@ -710,6 +822,7 @@ int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *
         return bb::fail(BB_ERR_INVALID,
                         "bb_solver_set_wish_sparse: an entry falls in a tile that is not in the "
                         "solver's tile list");
+    BB_TRY(refresh_full(s));
     s->have_wish = true;
     return BB_OK;
 }
@@ -730,6 +843,7 @@ int bb_solver_set_wish_from_coords(bb_solver *s, const double *xstar) {
 #undef BB_GEN
     }
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    BB_TRY(refresh_full(s));
     s->have_wish = true;
     return BB_OK;
 }
@@ -779,6 +893,19 @@ int bb_solver_iterate(bb_solver *s, int64_t iters, double lr) {
     if (s->hist_n + iters > s->hist_cap)
         return bb::fail(BB_ERR_STATE, "bb_solver_iterate: stress history full");
     BB_TRY(bb::enter_device(s->device));
+    if (s->row_owner) {
+        // one launch per iteration; launch k also folds the stress of launch k-1
+        for (int64_t k = 0; k < iters; ++k) {
+            hipEvent_t *ev = timing_slot(s);
+            if (ev) BB_HIP_CHECK(hipEventRecord(ev[0], s->stream));
+            BB_TRY(launch_row_owner(s, lr, k > 0, true));
+            if (ev) BB_HIP_CHECK(hipEventRecord(ev[1], s->stream));
+            if (ev) BB_HIP_CHECK(hipEventRecord(ev[2], s->stream));
+            s->hist_n++;
+        }
+        if (iters > 0) BB_TRY(launch_row_owner(s, lr, true, false));
+        return BB_OK;
+    }
     for (int64_t k = 0; k < iters; ++k) {
         hipEvent_t *ev = timing_slot(s);
         if (ev) BB_HIP_CHECK(hipEventRecord(ev[0], s->stream));
@@ -1294,7 +1421,8 @@ int bb_solver_measure_stream_read(bb_solver *s, int launches, double *ms_avg) {
     auto launch = [&]() {
         return bb::launch(s->nontemporal ? stream_read_kernel<true> : stream_read_kernel<false>,
                           dim3(s->n_waves / 4), dim3(256), 0, s->stream,
-                          (const float4 *)s->d_units, s->d_wave_range, (float *)s->d_f64_tmp);
+                          (const float4 *)s->d_units, s->chunk_q, s->chunk_r,
+                          (float *)s->d_f64_tmp);
     };
     BB_HIP_CHECK(launch());  // warm-up
     BB_HIP_CHECK(hipEventRecord(e0, s->stream));
@@ -1308,6 +1436,22 @@ int bb_solver_measure_stream_read(bb_solver *s, int launches, double *ms_avg) {
     *ms_avg = ms / launches;
     return BB_OK;
 }
+
+#ifdef BB_WAVE_TRACE
+// Diagnostic build only: the stamps of the last stress_grad_kernel launch,
+// 5 x uint64 per wave {start, first unit done, last unit consumed, end, xcc<<32 | hw_id}.
+BB_API int bb_solver_debug_wave_trace(bb_solver *s, unsigned long long *out, int64_t cap,
+                                      int64_t *n_waves) {
+    BB_REQUIRE(s != nullptr && n_waves != nullptr, "bb_solver_debug_wave_trace: NULL argument");
+    BB_TRY(bb::enter_device(s->device));
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    *n_waves = s->n_waves;
+    if (out && cap >= 5 * (int64_t)s->n_waves)
+        BB_HIP_CHECK(hipMemcpy(out, s->d_stresspart + s->n_waves, (size_t)s->n_waves * 40,
+                               hipMemcpyDeviceToHost));
+    return BB_OK;
+}
+#endif
 
 int bb_solver_traffic(const bb_solver *s, int64_t *unit_bytes, int64_t *pairs_dense) {
     BB_REQUIRE(s != nullptr, "bb_solver_traffic: solver is NULL");

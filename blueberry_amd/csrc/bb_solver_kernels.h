@@ -495,6 +495,25 @@ __device__ __forceinline__ void store_strip(const T (&gc)[(Lay<T, W>::LPR)][Trai
     }
 }
 
+// Diagnostic build only (-DBB_WAVE_TRACE): time stamp k of wave w, 10-ns ticks of the
+// constant-rate clock, into a region of its own behind the per-wave stress partials
+// (nothing reads it but bb_solver_debug_wave_trace).  Folds away in the product build.
+__device__ __forceinline__ void wave_stamp(double *stresspart, int n_waves, int w, int k) {
+    if constexpr (abl::kWaveTrace) {
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long *t = reinterpret_cast<unsigned long long *>(stresspart + n_waves);
+            unsigned long long v = (unsigned long long)wall_clock64();
+            if (k == 4) {     // where the wave ran: XCC id | HW_ID
+                unsigned xcc, hw;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                v = ((unsigned long long)xcc << 32) | hw;
+            }
+            t[(long long)w * 5 + k] = v;
+        }
+    }
+}
+
 // One wave = one contiguous chunk of units; 4 independent waves per workgroup.
 // No LDS, no barriers, no atomics: results are bitwise reproducible.
 //
@@ -504,7 +523,7 @@ __device__ __forceinline__ void store_strip(const T (&gc)[(Lay<T, W>::LPR)][Trai
 //   units      this rank's units, 8 KiB (RPU rows x VW columns) each
 //   X          (n_pad, 3) coordinates
 //   udesc      per local unit {i0, j0}
-//   wave_range per wave {first, end} local unit indices
+//   chunk_q/_r units per wave: n_local = n_waves * q + r, the first r waves take q + 1
 //   wave_slot  first column-partial slot of each wave
 //   rowpart    3*RPU elements per unit, base shifted to the rank's first tile
 //   colpart    3*VW elements per slot
@@ -524,16 +543,20 @@ __device__ __forceinline__ void store_strip(const T (&gc)[(Lay<T, W>::LPR)][Trai
 template <typename T, bool W, bool NT, int OP, bool DEFER>
 __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
     const T *__restrict__ units, const T *__restrict__ X, const int2 *__restrict__ udesc,
-    const int2 *__restrict__ wave_range, const int32_t *__restrict__ wave_slot,
-    T *__restrict__ rowpart, T *__restrict__ colpart, double *__restrict__ stresspart,
-    int cap_units) {
+    int chunk_q, int chunk_r, const int32_t *__restrict__ wave_slot, T *__restrict__ rowpart,
+    T *__restrict__ colpart, double *__restrict__ stresspart, int cap_units) {
     using Vec = typename Traits<T>::Vec;
     constexpr int VPL = Traits<T>::VPL;
     constexpr int VW = Lay<T, W>::VW;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int2 range = wave_range[w];
-    const int ua = range.x, ub = range.y;
+    // wave w owns units [w*q + min(w, r), +q (+1 if w < r)): arithmetic, not a table --
+    // one dependent memory round trip less before the wave's first matrix load
+    const int ua = w * chunk_q + (w < chunk_r ? w : chunk_r);
+    const int ub = ua + chunk_q + (w < chunk_r ? 1 : 0);
+    const int n_waves_all = gridDim.x * 4;
+    wave_stamp(stresspart, n_waves_all, w, 0);      // (diagnostic build only)
+    wave_stamp(stresspart, n_waves_all, w, 4);
     double stress = 0.0;
     // DEFER: this wave's parking space, cap_units * 12 floats + 4 dummy words
     extern __shared__ __attribute__((aligned(16))) float row_lds[];
@@ -653,6 +676,7 @@ __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
             const int curj = dc.y;
             strip_load(curj);
             unit_step(u);
+            if (u == ua) wave_stamp(stresspart, n_waves_all, w, 1);   // first unit done
             ++u;
             while (u < ub && dc.y == curj) {
                 unit_step(u);
@@ -662,6 +686,7 @@ __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
             ++slot;
             if (u >= ub) break;
         }
+        wave_stamp(stresspart, n_waves_all, w, 2);                    // last unit consumed
         if constexpr (DEFER && sizeof(T) == 4) {
             // the chunk's row sums, (ub - ua) * 12 floats, in one contiguous burst.
             // Lanes read what other lanes of this wave parked: LDS operations of one
@@ -681,6 +706,7 @@ __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) stress += __shfl_down(stress, off, 64);
     if (lane == 0) stresspart[w] = stress;
+    wave_stamp(stresspart, n_waves_all, w, 3);                        // partials issued
 }
 
 // --------------------------------------------------------------------------
@@ -742,13 +768,20 @@ struct ReduceParams {
     T lr;
 };
 
+constexpr int kRedWG = 128;  // threads per reduce workgroup = elements it sums
+// Grid: x = the block (or stage-1 slice) of the list, y = which kRedWG of the block's
+// 3*vw elements.  One element per thread: a thread's whole slice -- up to kBatch chunks
+// -- is in flight before its first add, so a launch costs about one memory round trip,
+// and a problem of B blocks puts B * (3*vw/128) workgroups on the chip instead of B
+// (N=17,700: 35 blocks used 35 CUs and 18 us for the two stages).
 template <typename T, bool W>
-__global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
+__global__ __launch_bounds__(kRedWG) void reduce_kernel(ReduceParams<T> p) {
     constexpr int CH = 3 * Lay<T, W>::VW;
-    constexpr int NE = (CH + 255) / 256;
+    static_assert(CH % kRedWG == 0, "3*vw is a multiple of the workgroup size");
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
-    __shared__ __attribute__((aligned(16))) T push_stage[CH];   // peer mode only
+    const int e = (int)blockIdx.y * kRedWG + tid;      // element of the block, < CH
+    __shared__ __attribute__((aligned(16))) T push_stage[kRedWG];   // peer mode only
     // peer mode: once this rank's exchange has failed it stops delivering (the status
     // word is only ever written by peer_wait_kernel, i.e. between launches: uniform)
     const bool peer_live =
@@ -756,75 +789,56 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
         __hip_atomic_load(&p.peer_state->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
     if (p.mode != kReduceStressOnly) {
         const int64_t k0 = p.blk_ptr[b], k1 = p.blk_ptr[b + 1];
-        T acc[NE];
-#pragma unroll
-        for (int j = 0; j < NE; ++j) acc[j] = T(0);
-        // Chunks are summed in list order (deterministic).  A whole slice of up to
-        // kReduceSlice chunks is loaded before the first add, so a slice costs one
-        // memory round trip, not one per chunk: this kernel is latency-bound.
-        // (fp64: half as many chunks per round trip, for the same 96 VGPRs of loads)
-        constexpr int kBatch = kReduceSlice * 4 / (int)sizeof(T);
+        T acc = T(0);
+        // Chunks are summed in list order (deterministic).
+        constexpr int kBatch = kReduceSlice;
         for (int64_t k = k0; k < k1; k += kBatch) {
-            T v[kBatch][NE];
+            T v[kBatch];
 #pragma unroll
             for (int q = 0; q < kBatch; ++q) {
                 const bool on = k + q < k1;
-                const T *src = p.part + p.blk_chunk[on ? k + q : k0];
-#pragma unroll
-                for (int j = 0; j < NE; ++j) {
-                    const int e = tid + 256 * j;
-                    v[q][j] = (on && e < CH) ? src[e] : T(0);
-                }
+                v[q] = on ? p.part[p.blk_chunk[on ? k + q : k0] + e] : T(0);
             }
 #pragma unroll
-            for (int q = 0; q < kBatch; ++q)
-#pragma unroll
-                for (int j = 0; j < NE; ++j) acc[j] += v[q][j];
+            for (int q = 0; q < kBatch; ++q) acc += v[q];
         }
-#pragma unroll
-        for (int j = 0; j < NE; ++j) {
-            const int e = tid + 256 * j;
-            if (e < CH) {
-                const int64_t o = (int64_t)b * CH + e;
-                if (p.mode == kReducePartial) {
-                    p.part_out[o] = acc[j];
-                } else {
-                    const T g = p.scale * acc[j];
-                    if (p.mode == kReduceApply) {
-                        // SPEC 2.4: V <- mu V - lr g ; X <- X + V   (mu = 0: X -= lr g)
-                        const T v = p.mu * p.V[o] - p.lr * g;
-                        p.V[o] = v;
-                        p.X[o] += v;
-                    } else if (p.mode == kReducePeer) {
-                        push_stage[e] = g;
-                    } else {
-                        p.exch[o] = g;
-                    }
-                }
+        const int64_t o = (int64_t)b * CH + e;
+        if (p.mode == kReducePartial) {
+            p.part_out[o] = acc;
+        } else {
+            const T g = p.scale * acc;
+            if (p.mode == kReduceApply) {
+                // SPEC 2.4: V <- mu V - lr g ; X <- X + V   (mu = 0: X -= lr g)
+                const T v = p.mu * p.V[o] - p.lr * g;
+                p.V[o] = v;
+                p.X[o] += v;
+            } else if (p.mode == kReducePeer) {
+                push_stage[tid] = g;
+            } else {
+                p.exch[o] = g;
             }
         }
         if (p.mode == kReducePeer && peer_live) {
-            // the block's 3*vw values go out as 16-byte stores, 1 KiB per wave
-            // instruction and peer: what crosses xGMI is long contiguous bursts
+            // the workgroup's values go out as 16-byte stores, one wave instruction per
+            // peer: what crosses xGMI is 512-byte (fp32) / 1-KiB (fp64) bursts
             typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
-            constexpr int NV = CH * (int)sizeof(T) / 16;
+            constexpr int NV = kRedWG * (int)sizeof(T) / 16;
             __syncthreads();
-            const vec_t *src = (const vec_t *)push_stage;
-            for (int v = tid; v < NV; v += 256) {
-                const vec_t val = src[v];
+            if (tid < NV) {
+                const vec_t val = ((const vec_t *)push_stage)[tid];
                 for (int q = 0; q < p.n_peers; ++q)
-                    ((vec_t *)(p.peer->dst[q] + (int64_t)b * CH))[v] = val;
+                    ((vec_t *)(p.peer->dst[q] + (int64_t)b * CH + (int64_t)blockIdx.y * kRedWG))[tid] = val;
             }
         }
     }
     if (p.mode == kReducePartial) return;
-    if (b == 0) {
-        __shared__ double sh[256];
+    if (b == 0 && blockIdx.y == 0) {
+        __shared__ double sh[kRedWG];
         double s = 0.0;
-        for (int i = tid; i < p.n_waves; i += 256) s += p.stresspart[i];
+        for (int i = tid; i < p.n_waves; i += kRedWG) s += p.stresspart[i];
         sh[tid] = s;
         __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
+        for (int off = kRedWG / 2; off > 0; off >>= 1) {
             if (tid < off) sh[tid] += sh[tid + off];
             __syncthreads();
         }
@@ -851,7 +865,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(ReduceParams<T> p) {
         __shared__ int last;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope
         __syncthreads();
-        if (tid == 0) last = atomicAdd(p.peer_counter, 1u) == gridDim.x - 1;
+        if (tid == 0) last = atomicAdd(p.peer_counter, 1u) == gridDim.x * gridDim.y - 1;
         __syncthreads();
         if (last) {
             if (tid == 0) atomicExch(p.peer_counter, 0u);
@@ -993,6 +1007,34 @@ __global__ __launch_bounds__(256) void convert_units_kernel(
     }
 }
 
+// A (d, d) float64 matrix that is ALREADY in HBM (a device-resident ContactMap,
+// bb_cm_*) -> this rank's units, device to device: the same conversion as
+// convert_units_kernel without the staging copy.  Only elements j > i are read.
+template <typename T, bool W>
+__global__ __launch_bounds__(256) void pack_units_from_matrix_kernel(
+    const double *__restrict__ m, int64_t ld, T *__restrict__ units_out,
+    const int2 *__restrict__ udesc, int64_t n_bins, int kind, double neg_inv_alpha) {
+    constexpr int VW = Lay<T, W>::VW, RPU = Lay<T, W>::RPU;
+    const int64_t ul = blockIdx.x;
+    const int2 dsc = udesc[ul];
+    T *out = units_out + ul * (RPU * VW);
+    for (int e = threadIdx.x; e < RPU * VW; e += 256) {
+        const int r = e / VW, c = e % VW;
+        const int64_t i = (int64_t)dsc.x + r, j = (int64_t)dsc.y + c;
+        double v = 0.0;
+        if (j > i && j < n_bins) {
+            v = m[i * ld + j];
+            const bool ok = (v > 0.0) && (v <= 1.7976931348623157e308);  // finite, positive
+            if (!ok)
+                v = 0.0;
+            else if (kind == BB_KIND_COUNTS)
+                v = pow(v, neg_inv_alpha);
+        }
+        if (sizeof(T) == 4 && v < 1e-30) v = 0.0;
+        out[e] = (T)v;
+    }
+}
+
 // Sparse (i, j, value) entries -> resident units (blocked-sparse input).  The
 // units were zeroed ("no constraint") first.  tilemap[I * n_blocks + J] is the
 // tile's index in the global list or -1.
@@ -1072,16 +1114,154 @@ __global__ __launch_bounds__(256) void gen_units_kernel(const double *__restrict
     }
 }
 
+// --------------------------------------------------------------------------
+// row-owner path: small maps, one launch per iteration
+// --------------------------------------------------------------------------
+// For a map whose whole symmetric matrix stays in the caches (N up to a few thousand
+// bins: chr21 at 50 kb is 963) the unit sweep above is launch-bound -- three dependent
+// launches per iteration, two of them only to add up partial sums.  Here BOTH
+// triangles are stored (`full`, n rows of `ld` elements, ld a multiple of 128, zero
+// = no constraint, zero diagonal) and one wave owns one bin i: it reads row i and the
+// coordinates X_k of every bin, so g_i is complete inside the wave -- no partial sums,
+// no reduce launch, no atomics, and a fixed summation order.  X_{k+1} goes to a second
+// buffer (the other waves are still reading X_k), so one launch is one iteration.
+// Every pair is evaluated twice (once from each end), which at these sizes is cheaper
+// than the two extra launches it saves.
+//
+// Stress: S(X_k) = 1/2 sum_i sum_j res_ij^2.  Each workgroup leaves the sum over its
+// four rows in part_out[block]; the fold is done by ONE extra workgroup of the NEXT
+// launch (blockIdx = gridDim - 1; it runs beside that launch's row workgroups) and by a
+// fold-only launch after the last iteration of a bb_solver_iterate call.
+template <typename T>
+__device__ __forceinline__ void pair_row(T delta, T xi, T yi, T zi, T xj, T yj, T zj, T &gx,
+                                         T &gy, T &gz, T &s) {
+    const T dx = xi - xj, dy = yi - yj, dz = zi - zj;
+    const T d2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, Traits<T>::eps2())));  // SPEC 2.2
+    T rinv, dist;
+    if constexpr (sizeof(T) == 4) {
+        rinv = __builtin_amdgcn_rsqf(d2);
+        dist = d2 * rinv;
+    } else {
+        T r = __builtin_amdgcn_rsq(d2);      // as pair_step<double>
+        const T h = T(0.5) * d2;
+        r = r * fma(-h * r, r, T(1.5));
+        r = r * fma(-h * r, r, T(1.5));
+        dist = d2 * r;
+        dist = fma(T(0.5) * r, fma(-dist, dist, d2), dist);
+        rinv = r;
+    }
+    const T res = delta > T(0) ? dist - delta : T(0);
+    s = fma(res, res, s);
+    const T coef = res * rinv;
+    gx = fma(coef, dx, gx);
+    gy = fma(coef, dy, gy);
+    gz = fma(coef, dz, gz);
+}
+
+constexpr int kRowTrip = 128;   // columns per loop trip of a wave: 2 per lane
+
+// WPR waves share one row (1, 2 or 4: the host picks it so that a small map still
+// puts >= 16 waves on every CU): wave part p takes the 128-column trips p, p + WPR, ...;
+// the parts meet in LDS and are added in part order by the row's first wave.
+template <typename T, int WPR>
+__global__ __launch_bounds__(256) void row_owner_kernel(
+    const T *__restrict__ full, int64_t ld, int n, const T *__restrict__ Xin,
+    T *__restrict__ Xout, T *__restrict__ V, T lr, T mu, const double *__restrict__ part_prev,
+    int n_prev, double *__restrict__ hist_prev, double *__restrict__ part_out) {
+    constexpr int ROWS = 4 / WPR;                 // rows per workgroup
+    __shared__ double sh[256];
+    __shared__ T red[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (blockIdx.x == gridDim.x - 1) {
+        // the fold workgroup: stress of the PREVIOUS launch, fixed order
+        if (hist_prev == nullptr) return;
+        double a = 0.0;
+        for (int q = tid; q < n_prev; q += 256) a += part_prev[q];
+        sh[tid] = a;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) sh[tid] += sh[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) *hist_prev = 0.5 * sh[0];
+        return;
+    }
+    const int i = blockIdx.x * ROWS + wv / WPR;
+    const int part = wv % WPR;
+    T s = T(0), gx = T(0), gy = T(0), gz = T(0);
+    T xi = T(0), yi = T(0), zi = T(0);
+    if (i < n) {
+        xi = Xin[3 * (int64_t)i]; yi = Xin[3 * (int64_t)i + 1]; zi = Xin[3 * (int64_t)i + 2];
+        const T *row = full + (int64_t)i * ld;
+#pragma unroll 4
+        for (int c = part * kRowTrip; c < (int)ld; c += WPR * kRowTrip) {
+#pragma unroll
+            for (int u = 0; u < kRowTrip / 64; ++u) {
+                const int j = c + 64 * u + lane;
+                const T *xj = Xin + 3 * (int64_t)j;
+                pair_row<T>(row[j], xi, yi, zi, xj[0], xj[1], xj[2], gx, gy, gz, s);
+            }
+        }
+        wave_sum_hi3(gx, gy, gz);
+        s = wave_sum_hi(s);
+    }
+    if constexpr (WPR > 1) {
+        if (lane == 63) { red[wv][0] = gx; red[wv][1] = gy; red[wv][2] = gz; red[wv][3] = s; }
+        __syncthreads();
+        if (part == 0 && lane == 63) {
+#pragma unroll
+            for (int p = 1; p < WPR; ++p) {
+                gx += red[wv + p][0]; gy += red[wv + p][1]; gz += red[wv + p][2];
+                s += red[wv + p][3];
+            }
+        }
+    }
+    if (i < n && part == 0 && lane == 63) {
+        // SPEC 2.3 / 2.4: g = 2 * sum; V <- mu V - lr g; X <- X + V
+        const int64_t o = 3 * (int64_t)i;
+        const T vx = mu * V[o] - lr * (T(2) * gx);
+        const T vy = mu * V[o + 1] - lr * (T(2) * gy);
+        const T vz = mu * V[o + 2] - lr * (T(2) * gz);
+        V[o] = vx; V[o + 1] = vy; V[o + 2] = vz;
+        Xout[o] = xi + vx; Xout[o + 1] = yi + vy; Xout[o + 2] = zi + vz;
+    }
+    if (lane == 63) sh[wv] = (part == 0 && i < n) ? (double)s : 0.0;
+    __syncthreads();
+    if (tid == 0) part_out[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// resident units -> both triangles of the full matrix (zeroed first; one-off)
+template <typename T, bool W>
+__global__ __launch_bounds__(256) void units_to_full_kernel(const T *__restrict__ units,
+                                                            const int2 *__restrict__ udesc,
+                                                            T *__restrict__ full, int64_t ld,
+                                                            int64_t n_bins) {
+    constexpr int VW = Lay<T, W>::VW, RPU = Lay<T, W>::RPU;
+    const int64_t ul = blockIdx.x;
+    const int2 dsc = udesc[ul];
+    const T *in = units + ul * (RPU * VW);
+    for (int e = threadIdx.x; e < RPU * VW; e += 256) {
+        const int r = e / VW, c = e % VW;
+        const int64_t i = (int64_t)dsc.x + r, j = (int64_t)dsc.y + c;
+        if (j > i && j < n_bins) {
+            const T v = in[e];
+            full[i * ld + j] = v;
+            full[j * ld + i] = v;
+        }
+    }
+}
+
 // Measurement only: the same waves read the same units with the same rolling
 // 8-row window, but do nothing with the data except fold it into a checksum --
 // the practical HBM read ceiling for this access pattern on this box.
 template <bool NT>
 __global__ __launch_bounds__(256, 4) void stream_read_kernel(const float4 *__restrict__ units,
-                                                             const int2 *__restrict__ wave_range,
+                                                             int chunk_q, int chunk_r,
                                                              float *__restrict__ sink) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int ua = wave_range[w].x, ub = wave_range[w].y;
+    const int ua = w * chunk_q + (w < chunk_r ? w : chunk_r);
+    const int ub = ua + chunk_q + (w < chunk_r ? 1 : 0);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ua < ub) {
         float4 d[8];

@@ -20,7 +20,10 @@ Deviations from the reference, all deliberate:
   * `filter` also updates `n_bins` (= rows kept) and `regions` (the reference
     leaves them stale, pyx:140-141) and drops the KR vectors, so a later
     `normalize()` raises instead of indexing out of bounds --
-    `keep_stale=True` restores the old behaviour.
+    `keep_stale=True` restores the old behaviour.  The matrix it leaves is bit
+    for bit the reference's (goldens `cm*_filter_*`).
+  * `matrix` is a lazily fetched attribute: the matrix lives in HBM (class
+    docstring); `to_host()`, `marginals()`, `from_triples()` are additions.
   * `normalize` raises ZeroDivisionError up front when a divisor would be 0
     (the reference raises from inside the loop, after modifying part of the
     matrix, because Cython checks float division; golden flag
@@ -40,21 +43,64 @@ KR_EXP = RAO + ("data/Rao-Cell2014/rawFromGEO/{0}/{2}kb_resolution_intrachromoso
 
 
 def scatter_triples(triples, resolution, n_bins, device=0):
-    """(n,3) [pos_i, pos_j, count] rows -> dense symmetric (n_bins+1)^2 matrix.
+    """(n,3) [pos_i, pos_j, count] rows -> dense symmetric (n_bins+1)^2 host matrix.
 
     GPU form of the loop at `blueberry/datatypes.pyx:110-116`: bin =
     int(pos / resolution), both [j,k] and [k,j] set, later rows win."""
-    t = numpy.nan_to_num(numpy.asarray(triples, dtype=numpy.float64))   # pyx:102
-    if t.ndim != 2 or t.shape[1] != 3:
-        raise ValueError("triples must have shape (n, 3)")
-    # the reference's pointer arithmetic reads the array column-major (pyx:111-113)
-    cols = numpy.ascontiguousarray(t.T)
-    d = int(n_bins) + 1
-    matrix = numpy.zeros((d, d), dtype=numpy.float64)                   # pyx:99
-    _lib.check(_lib.load().bb_contactmap_scatter(
-        _lib.as_f64_ptr(cols), t.shape[0], int(resolution), _lib.as_f64_ptr(matrix), d,
-        int(device)), "bb_contactmap_scatter")
-    return matrix
+    return _DeviceMatrix.from_triples(triples, resolution, n_bins, device).to_host()
+
+
+class _DeviceMatrix(object):
+    """Owner of one bb_cm handle: the (d, d) float64 matrix resident in HBM."""
+
+    def __init__(self, d, device):
+        self._lib = _lib.load()
+        self._h = _lib.c_void_p()
+        self.device = int(device)
+        _lib.check(self._lib.bb_cm_create(self._h, int(d), self.device), "bb_cm_create")
+
+    @classmethod
+    def from_triples(cls, triples, resolution, n_bins, device):
+        t = numpy.nan_to_num(numpy.asarray(triples, dtype=numpy.float64))   # pyx:102
+        if t.ndim != 2 or t.shape[1] != 3:
+            raise ValueError("triples must have shape (n, 3)")
+        # the reference's pointer arithmetic reads the array column-major (pyx:111-113)
+        cols = numpy.ascontiguousarray(t.T)
+        self = cls(int(n_bins) + 1, device)                                 # zeros, pyx:99
+        _lib.check(self._lib.bb_cm_scatter(self._h, _lib.as_f64_ptr(cols), t.shape[0],
+                                           int(resolution)), "bb_cm_scatter")
+        return self
+
+    @classmethod
+    def from_host(cls, matrix, device):
+        m = numpy.ascontiguousarray(matrix, dtype=numpy.float64)
+        self = cls(m.shape[0], device)
+        _lib.check(self._lib.bb_cm_upload(self._h, _lib.as_f64_ptr(m), m.shape[1]), "bb_cm_upload")
+        return self
+
+    @property
+    def d(self):
+        n = _lib.c_i64()
+        _lib.check(self._lib.bb_cm_dim(self._h, n), "bb_cm_dim")
+        return int(n.value)
+
+    def to_host(self):
+        d = self.d
+        out = numpy.empty((d, d), dtype=numpy.float64)
+        if d:
+            _lib.check(self._lib.bb_cm_download(self._h, _lib.as_f64_ptr(out), d), "bb_cm_download")
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.bb_cm_destroy(self._h)
+            self._h = _lib.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ContactMap(object):
@@ -74,6 +120,17 @@ class ContactMap(object):
     resolution, chromosome, celltype, filename, n_bins
     matrix : numpy.ndarray, shape=(n_bins+1, n_bins+1), float64
     regions : numpy.ndarray -- the midpoints found in this map
+
+    Where the matrix lives.  The reference keeps one host matrix alive across
+    `__init__` -> `normalize()` -> `filter()` -> consumer (pyx:97-120, :161-171,
+    :140-141).  Here that one matrix lives in HBM (`bb_cm_*`, include/blueberry_hip.h):
+    the constructor scatters the triples on the device, `normalize()` and `filter()`
+    work on the resident matrix in place, and `StructureSolver.fit(contact_map)` packs
+    it device to device -- no (n_bins+1)^2 host transfer anywhere on that path.
+    `matrix` is fetched lazily: reading the attribute downloads the matrix (once)
+    and, because the caller may then write into the array, makes the host copy the
+    authoritative one -- the next device operation uploads it again.  `to_host()`
+    returns a private copy and leaves the device copy authoritative.
     """
 
     def __init__(self, celltype, chromosome, resolution=1000, device=0):
@@ -90,9 +147,54 @@ class ContactMap(object):
         data = pandas.read_csv(self.filename, delimiter="\t", engine="c", dtype="float64",
                                header=None).values
         data = numpy.nan_to_num(data)
-        self.matrix = scatter_triples(data, self.resolution, self.n_bins, self.device)
+        self._host = None
+        self._dev = _DeviceMatrix.from_triples(data, self.resolution, self.n_bins, self.device)
         self.regions = numpy.union1d(data[:, 0], data[:, 1])
         self.regions.sort()
+
+    # -- where the matrix lives ------------------------------------------
+    @property
+    def matrix(self):
+        if self._host is None:
+            self._host = self._dev.to_host()
+        # the caller may write into it: from here on the host copy is the truth
+        if self._dev is not None:
+            self._dev.close()
+            self._dev = None
+        return self._host
+
+    @matrix.setter
+    def matrix(self, value):
+        self._host = value
+        if self._dev is not None:
+            self._dev.close()
+            self._dev = None
+
+    def to_host(self):
+        """A copy of the matrix; the resident one stays authoritative."""
+        if self._dev is not None:
+            return self._dev.to_host()
+        return numpy.array(self._host, dtype=numpy.float64)
+
+    @property
+    def is_resident(self):
+        """True while the authoritative matrix is the one in HBM."""
+        return self._dev is not None
+
+    def _resident(self):
+        """The device handle of the authoritative matrix (uploading a host one)."""
+        if self._dev is None:
+            m = numpy.ascontiguousarray(self._host, dtype=numpy.float64)
+            if m.ndim != 2 or m.shape[0] != m.shape[1]:
+                raise ValueError("matrix must be square")
+            self._dev = _DeviceMatrix.from_host(m, self.device)
+            self._host = None
+        return self._dev
+
+    @property
+    def shape(self):
+        d = self._dev.d if self._dev is not None else self._host.shape[0]
+        return (d, d)
 
     # ------------------------------------------------------------------
     @classmethod
@@ -124,11 +226,12 @@ class ContactMap(object):
                                   max(b1.max(), b2.max()) > self.n_bins):
             raise ValueError("a contact falls outside [0, n_bins]")
         d = self.n_bins + 1
-        self.matrix = numpy.zeros((d, d), dtype=numpy.float64)
+        m = numpy.zeros((d, d), dtype=numpy.float64)
         for k in range(contacts.shape[0]):          # later rows win, as in the reference
-            self.matrix[b1[k], b2[k]] = contacts[k, 2]
+            m[b1[k], b2[k]] = contacts[k, 2]
             if symmetric:
-                self.matrix[b2[k], b1[k]] = contacts[k, 2]
+                m[b2[k], b1[k]] = contacts[k, 2]
+        self._host, self._dev = m, None
         self.regions = numpy.union1d(contacts[:, 0], contacts[:, 1])
         self._KRnorm = None if KRnorm is None else numpy.asarray(KRnorm, dtype=numpy.float64)
         self._KRexpected = (None if KRexpected is None
@@ -145,7 +248,7 @@ class ContactMap(object):
             raise ValueError("matrix must be square")
         self.resolution, self.chromosome, self.celltype = int(resolution), chromosome, celltype
         self.device, self.filename = int(device), ""
-        self.matrix = m
+        self._host, self._dev = m, None
         self.n_bins = m.shape[0] - 1
         self.regions = numpy.arange(self.n_bins, dtype=numpy.float64) * self.resolution
         self._KRnorm = None if KRnorm is None else numpy.asarray(KRnorm, dtype=numpy.float64)
@@ -153,18 +256,52 @@ class ContactMap(object):
                             else numpy.asarray(KRexpected, dtype=numpy.float64))
         return self
 
+    @classmethod
+    def from_triples(cls, triples, resolution, n_bins, KRnorm=None, KRexpected=None, celltype="",
+                     chromosome=0, device=0):
+        """The file constructor without the files: Rao-format (n, 3) rows
+        [pos_i, pos_j, count] (what `__init__` reads, pyx:100-102), scattered on the
+        device; the matrix is never built on the host."""
+        self = cls.__new__(cls)
+        self.resolution, self.chromosome, self.celltype = int(resolution), chromosome, celltype
+        self.device, self.filename = int(device), ""
+        data = numpy.nan_to_num(numpy.asarray(triples, dtype=numpy.float64))
+        self.n_bins = int(n_bins)
+        self._host = None
+        self._dev = _DeviceMatrix.from_triples(data, self.resolution, self.n_bins, self.device)
+        self.regions = numpy.union1d(data[:, 0], data[:, 1])
+        self._KRnorm = None if KRnorm is None else numpy.asarray(KRnorm, dtype=numpy.float64)
+        self._KRexpected = (None if KRexpected is None
+                            else numpy.asarray(KRexpected, dtype=numpy.float64))
+        return self
+
     # ------------------------------------------------------------------
+    def marginals(self):
+        """`matrix.sum(axis=0)` of the resident matrix (pyx:140), bit for bit."""
+        dev = self._resident()
+        out = numpy.empty(dev.d, dtype=numpy.float64)
+        _lib.check(dev._lib.bb_cm_marginals(dev._h, _lib.as_f64_ptr(out)), "bb_cm_marginals")
+        return out
+
     def filter(self, threshold=0, keep_stale=False):
         """Remove rows and columns whose marginal count is <= threshold.
 
-        In place, returns None (`blueberry/datatypes.pyx:122-141`)."""
-        marginals = self.matrix.sum(axis=0)
-        keep = marginals > threshold
-        self.matrix = numpy.ascontiguousarray(self.matrix[keep][:, keep])
+        In place, returns None (`blueberry/datatypes.pyx:122-141`); runs on the GPU on
+        the resident matrix: column sums in numpy's summation order, prefix-sum
+        compaction, gather."""
+        dev = self._resident()
+        d = dev.d
+        keep = numpy.zeros(d, dtype=numpy.uint8)
+        dn = _lib.c_i64()
+        import ctypes
+        _lib.check(dev._lib.bb_cm_filter(dev._h, float(threshold), dn,
+                                         keep.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))),
+                   "bb_cm_filter")
+        keep = keep.astype(bool)
         if not keep_stale:
             # bins that survive, in the old numbering; the zero padding row
             # (index n_bins) never survives threshold >= 0
-            self.n_bins = int(self.matrix.shape[0])
+            self.n_bins = int(dn.value)
             if self.regions is not None and self.regions.shape[0]:
                 bins = (self.regions / self.resolution).astype(numpy.int64)
                 ok = (bins >= 0) & (bins < keep.shape[0])
@@ -178,11 +315,12 @@ class ContactMap(object):
         """KR matrix balancing and observed/expected normalisation, in place.
 
         m[j, j+i] /= KRnorm[j] * KRnorm[j+i] * KRexpected[i], mirrored, then
-        nan_to_num (`blueberry/datatypes.pyx:143-171`); runs on the GPU."""
+        nan_to_num (`blueberry/datatypes.pyx:143-171`); runs on the GPU on the
+        resident matrix."""
         if self._KRnorm is None or self._KRexpected is None:
             raise ValueError("normalize() needs KRnorm and KRexpected")
         n = self.n_bins
-        if self.matrix.shape != (n + 1, n + 1):
+        if self.shape != (n + 1, n + 1):
             raise ValueError("matrix shape does not match n_bins (was filter() used with "
                              "keep_stale=True?)")
         if self._KRnorm.shape[0] < n or self._KRexpected.shape[0] < n:
@@ -191,11 +329,9 @@ class ContactMap(object):
         ke = numpy.ascontiguousarray(self._KRexpected[:n], dtype=numpy.float64)
         if n and (numpy.any(kr == 0.0) or numpy.any(ke == 0.0)):
             raise ZeroDivisionError("float division")
-        m = numpy.ascontiguousarray(self.matrix, dtype=numpy.float64)
-        _lib.check(_lib.load().bb_contactmap_normalize(
-            _lib.as_f64_ptr(m), n, _lib.as_f64_ptr(kr), _lib.as_f64_ptr(ke), self.device),
-            "bb_contactmap_normalize")
-        self.matrix = m
+        dev = self._resident()
+        _lib.check(dev._lib.bb_cm_normalize(dev._h, n, _lib.as_f64_ptr(kr), _lib.as_f64_ptr(ke)),
+                   "bb_cm_normalize")
 
     def correlation(self):
         """Convert the map to a correlation map, in place (pyx:173-188)."""
@@ -210,12 +346,13 @@ class ContactMap(object):
         plt.ylabel("Genomic Coordinate (kb)", fontsize=14)
         plt.xticks(fontsize=14)
         plt.yticks(fontsize=14)
-        plt.imshow(numpy.arcsinh(self.matrix) if arcsinh else self.matrix, **kwargs)
+        m = self.to_host()
+        plt.imshow(numpy.arcsinh(m) if arcsinh else m, **kwargs)
 
     def eigenvector(self):
         """First eigenvector of the matrix (restarted Lanczos, pyx:216-235)."""
         import scipy.sparse.linalg
-        _, eigenvectors = scipy.sparse.linalg.eigsh(self.matrix, k=1)
+        _, eigenvectors = scipy.sparse.linalg.eigsh(self.to_host(), k=1)
         return eigenvectors[:, 0]
 
 

@@ -76,6 +76,12 @@ class HipEngine(object):
             self._h, _lib.as_f64_ptr(m), m.strides[0] // 8, _KINDS[kind], float(alpha)),
             "bb_solver_set_wish_dense")
 
+    def set_wish_from_cm(self, dev_matrix, kind, alpha):
+        """Device to device from a resident ContactMap matrix (datatypes._DeviceMatrix)."""
+        _lib.check(self._lib.bb_solver_set_wish_from_cm(self._h, dev_matrix._h, _KINDS[kind],
+                                                        float(alpha)),
+                   "bb_solver_set_wish_from_cm")
+
     def set_wish_sparse(self, rows, cols, vals, kind, alpha, KRnorm=None, KRexpected=None):
         r = numpy.ascontiguousarray(rows, dtype=numpy.int64)
         c = numpy.ascontiguousarray(cols, dtype=numpy.int64)
@@ -483,6 +489,10 @@ class StructureSolver(object):
         scipy.sparse matrix (symmetric; either triangle is enough; of several
         COO entries for one pair the last is kept) -- the sparse form never builds
         the dense matrix."""
+        if getattr(X, "is_resident", False) and hasattr(self._engine_factory, "set_wish_from_cm"):
+            # a ContactMap whose matrix lives in HBM: packed device to device
+            n = X.shape[0]
+            return self._fit_impl(X, n, init, None, None)
         matrix = getattr(X, "matrix", X)
         sparse = hasattr(matrix, "tocoo")          # any scipy.sparse matrix
         if sparse:
@@ -495,7 +505,8 @@ class StructureSolver(object):
         return self._fit_impl(matrix, n, init, None, None)
 
     def _fit_impl(self, matrix, n, init, KRnorm, KRexpected):
-        sparse = hasattr(matrix, "row")
+        resident = getattr(matrix, "is_resident", False)
+        sparse = hasattr(matrix, "row") and not resident
         if n < 2:
             raise ValueError("need at least 2 bins")
         rank, world = _dist_state(self.distributed)
@@ -512,7 +523,13 @@ class StructureSolver(object):
         eng = self._engine_factory(n, self.dtype, rank=rank, world=world,
                                    device=self._pick_device(world), tiles=tiles)
         try:
-            if sparse:
+            if resident:
+                dev = matrix._resident()
+                if dev.device != eng.device:
+                    raise ValueError("the ContactMap lives on device %d, the solver runs on %d"
+                                     % (dev.device, eng.device))
+                eng.set_wish_from_cm(dev, self.kind, self.alpha)
+            elif sparse:
                 eng.set_wish_sparse(rows, cols, vals, self.kind, self.alpha, KRnorm, KRexpected)
             else:
                 eng.set_wish_dense(matrix, self.kind, self.alpha)

@@ -269,9 +269,46 @@ BB_API int bb_solver_measure_stream_read(bb_solver *s, int launches, double *ms_
 BB_API int bb_solver_traffic(const bb_solver *s, int64_t *unit_bytes, int64_t *pairs_dense);
 
 /* ---------------------------------------------------------------------- */
-/* A2/A3  ContactMap build + normalise on the device                        */
-/*        (reference: blueberry/datatypes.pyx:97-116 and :161-171)          */
+/* A2/A3/A4  the ContactMap stage, resident on the device                   */
+/*        (reference: blueberry/datatypes.pyx:97-116, :161-171, :122-141)   */
 /* ---------------------------------------------------------------------- */
+
+/* One (d, d) float64 matrix, d = n_bins + 1, that stays in HBM across
+ * scatter -> normalize -> filter -> solver, as `ContactMap.matrix` stays in host
+ * memory across the same calls in the reference (datatypes.pyx:97-120, :161-171,
+ * :140-141).  No matrix-sized host transfer happens unless the caller asks for
+ * one (bb_cm_upload / bb_cm_download).  Every operation is bit-exact fp64. */
+typedef struct bb_cm bb_cm;
+BB_API int bb_cm_create(bb_cm **out, int64_t d, int device);   /* zero-filled (pyx:99) */
+BB_API int bb_cm_destroy(bb_cm *cm);
+BB_API int bb_cm_dim(const bb_cm *cm, int64_t *d);
+/* The resident matrix itself (row-major, leading dimension d) for callers that share
+ * the HIP context; borrowed, valid until the next bb_cm_filter / bb_cm_destroy. */
+BB_API int bb_cm_device_ptr(const bb_cm *cm, const double **dev_matrix, int64_t *d, int *device);
+BB_API int bb_cm_upload(bb_cm *cm, const double *matrix, int64_t ld);   /* host (d,d) -> device */
+BB_API int bb_cm_download(bb_cm *cm, double *matrix, int64_t ld);       /* device -> host (d,d) */
+/* ContactMap.__init__'s loop (pyx:110-116): zero the matrix, then for every triple
+ * (column-major `triples`, as bb_contactmap_scatter) set [j][k] and [k][j]; later
+ * triples overwrite earlier ones.  Needs no scratch the size of the matrix. */
+BB_API int bb_cm_scatter(bb_cm *cm, const double *triples, int64_t n, int32_t resolution);
+/* ContactMap.normalize (pyx:161-171), in place: m[j][j+i] /= KRnorm[j]*KRnorm[j+i]*
+ * KRexpected[i], mirrored, then nan_to_num over the whole matrix.  d must be n_bins+1. */
+BB_API int bb_cm_normalize(bb_cm *cm, int64_t n_bins, const double *KRnorm,
+                           const double *KRexpected);
+/* Column marginals `matrix.sum(axis=0)` (pyx:140), d doubles to the host: rows are
+ * added in order, which is bit for bit what numpy computes. */
+BB_API int bb_cm_marginals(bb_cm *cm, double *sums);
+/* ContactMap.filter (pyx:140-141): keep the rows and columns whose marginal is
+ * > threshold (a NaN marginal is dropped, as `NaN > t` is false in numpy).  The
+ * resident matrix becomes (d_new, d_new); keep_out (d bytes, may be NULL) receives the
+ * 0/1 mask over the OLD indices. */
+BB_API int bb_cm_filter(bb_cm *cm, double threshold, int64_t *d_new, uint8_t *keep_out);
+/* Hand the resident matrix to a solver of n_bins = d bins on the same device, device
+ * to device (same meaning of kind / alpha as bb_solver_set_wish_dense). */
+BB_API int bb_solver_set_wish_from_cm(bb_solver *s, const bb_cm *cm, int kind, double alpha);
+
+/* The same two loops around a HOST matrix (round-1 entry points; upload, kernel,
+ * download): */
 
 /* matrix (d,d) float64 host, d = n_bins+1, zero-filled on entry.  `triples`
  * is the (n,3) array exactly as the reference's pointer arithmetic reads it:

@@ -225,7 +225,7 @@ for name, world, comm in (("fused", 1, None), ("exchange", 2, "rccl"), ("torch",
     if comm == "auto":
         # the trial: both transports from the same start, coordinates compared, the
         # faster one kept, the start restored
-        state = select_exchange(e, lr)
+        state = select_exchange(e, lr, trial=True)
         assert state in ("peer", "rccl") and e._comm_trial["agree"], (state, e._comm_trial)
         assert numpy.array_equal(e.get_coords(), x0.astype(numpy.float32).astype(numpy.float64))
         assert e.stress_history().size == 0
@@ -233,6 +233,9 @@ for name, world, comm in (("fused", 1, None), ("exchange", 2, "rccl"), ("torch",
     else:
         run_iterations(e, k, lr, world)
         assert e._comm_state == comm, (e._comm_state, comm)
+        if comm == "rccl":
+            assert e.comm_world() == 1                  # what RCCL itself reports
+            e.sync_timeout(10000)
     out[name] = (e.get_coords(), e.stress_history()); e.close()
 assert numpy.array_equal(out["torch"][0], out["exchange"][0])      # same kernels, same sums
 assert numpy.array_equal(out["peer"][0], out["exchange"][0])       # one rank: nothing to reorder

@@ -60,6 +60,11 @@ def test_compute_fails_loudly_without_gpu():
                                    KRexpected=numpy.ones(2))
     with pytest.raises(RuntimeError, match="HIP device"):
         cm.normalize()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        cm.filter()                      # filter runs on the device too: no numpy stand-in
+    with pytest.raises(RuntimeError, match="HIP device"):
+        bb.ContactMap.from_triples(numpy.array([[0.0, 5000.0, 3.0]]), 5000, 4)
+    assert cm.matrix.shape == (3, 3)     # the host copy was never lost
     n = _lib.ctypes.c_int(5)
     assert _lib.load().bb_device_count(n) == _lib.BB_ERR_HIP and n.value == 0
 
@@ -195,19 +200,14 @@ def test_contactmap_from_arrays_and_filter():
     assert numpy.array_equal(cm.regions, [mids(0), mids(1), mids(3)])
     one_sided = bb.ContactMap.from_arrays("x", 1, res, contacts, n_bins=5, symmetric=False)
     assert one_sided.matrix[1, 0] == 0.0 and one_sided.matrix[0, 1] == 6.0
-    assert cm.filter() is None                                  # in place, returns None
-    assert cm.matrix.shape == (3, 3) and cm.n_bins == 3         # bins 0, 1, 3 survive
-    assert numpy.array_equal(cm.regions, [mids(0), mids(1), mids(3)])
-    with pytest.raises(ValueError):
-        cm.normalize()                                          # KR vectors gone after filter
     with pytest.raises(ValueError):
         bb.ContactMap.from_arrays("x", 1, res, numpy.array([[mids(9), mids(1), 1.0]]), n_bins=5)
-
-
-def test_contactmap_filter_keep_stale_matches_reference_quirk():
-    cm = bb.ContactMap.from_matrix(numpy.diag([1.0, 0.0, 2.0, 0.0]))
-    cm.filter(keep_stale=True)
-    assert cm.matrix.shape == (2, 2) and cm.n_bins == 3          # stale, as at datatypes.pyx:140
+    # the matrix attribute: assignment replaces it, to_host() copies it
+    cm.matrix = numpy.eye(6)
+    assert cm.shape == (6, 6) and not cm.is_resident
+    c = cm.to_host()
+    c[0, 0] = 9.0
+    assert cm.matrix[0, 0] == 1.0
 
 
 def test_contactmap_normalize_precheck_and_shapes():

@@ -1,0 +1,58 @@
+"""Throughput of the ContactMap stage on the resident matrix (A2/A3/A4 + the hand-over to
+the solver), d = n_bins + 1 = 24,927 (chr1 at 10 kb) unless sizes are given.  Wall clock
+around each C-ABI call (each call synchronises), inputs already in HBM except the triples
+and the KR vectors, which are what the call takes.  Algorithmic bytes:
+  scatter    24 B per triple read + 16 B written (two cells), + d^2 * 8 B zero fill
+  normalize  8 B read + 16 B written per upper pair  (d^2/2 pairs)
+  marginals  8 B per element (one pass over the matrix)
+  filter     marginals + 8 B read + 8 B written per kept element
+  pack       8 B read per upper pair + 4 B written (fp32 units)"""
+import os, sys, time
+import numpy
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import blueberry_amd as bb
+from blueberry_amd.solver import HipEngine
+
+def timed(fn, reps=3):
+    best = 1e9
+    for _ in range(reps):
+        t0 = time.perf_counter(); r = fn(); dt = time.perf_counter() - t0
+        best = min(best, dt)
+    return best, r
+
+for n_bins in [int(a) for a in sys.argv[1:]] or [24926]:
+    d = n_bins + 1
+    rng = numpy.random.default_rng(0)
+    nnz = min(40_000_000, d * 400)
+    bi = rng.integers(0, n_bins, nnz)
+    bj = numpy.minimum(n_bins - 1, bi + rng.geometric(0.002, nnz))
+    res = 10000
+    triples = numpy.stack([bi * float(res), bj * float(res), rng.integers(1, 500, nnz).astype(float)], 1)
+    kr = 0.5 + rng.random(n_bins); ke = 50.0 / (1.0 + numpy.arange(n_bins)) + 0.1
+    print("== n_bins %d (matrix %.2f GB fp64), %d triples" % (n_bins, d * d * 8 / 1e9, nnz))
+    t, cm = timed(lambda: bb.ContactMap.from_triples(triples, res, n_bins, KRnorm=kr, KRexpected=ke), 2)
+    print("scatter (H2D of the triples + zero fill + 2 passes)  %.1f ms  -> %.1f GB/s of %.2f GB"
+          % (t * 1e3, (nnz * 40 + d * d * 8) / t / 1e9, (nnz * 40 + d * d * 8) / 1e9))
+    def norm():
+        cm._KRnorm, cm._KRexpected = kr, ke
+        cm.normalize()
+    t, _ = timed(norm)
+    pairs = d * (d + 1) // 2
+    print("normalize (in place)                                 %.2f ms  -> %.0f GB/s algorithmic (24 B per upper pair), %.1f %% of 8 TB/s"
+          % (t * 1e3, pairs * 24 / t / 1e9, pairs * 24 / t / 8e12 * 100))
+    t, _ = timed(cm.marginals)
+    print("marginals (column sums in numpy's order, D2H of d)   %.2f ms  -> %.0f GB/s, %.1f %% of 8 TB/s"
+          % (t * 1e3, d * d * 8 / t / 1e9, d * d * 8 / t / 8e12 * 100))
+    lr = 1.0 / (2 * d)
+    eng = HipEngine(d, "float32")
+    t, _ = timed(lambda: eng.set_wish_from_cm(cm._resident(), "counts", 3.0))
+    print("pack into the solver's units, device to device       %.2f ms  -> %.0f GB/s algorithmic (12 B per upper pair)"
+          % (t * 1e3, pairs * 12 / t / 1e9))
+    eng.close()
+    t0 = time.perf_counter(); cm.filter(float(numpy.median(cm.marginals()))); t = time.perf_counter() - t0
+    dn = cm.shape[0]
+    print("filter at the median marginal (-> %d bins)          %.2f ms  -> %.0f GB/s algorithmic"
+          % (dn, t * 1e3, (d * d * 8 + dn * dn * 16) / t / 1e9))
+    t, m = timed(cm.to_host, 1)
+    print("fetch of the filtered matrix (D2H, %.2f GB)           %.1f ms  -> %.1f GB/s (PCIe)"
+          % (dn * dn * 8 / 1e9, t * 1e3, dn * dn * 8 / t / 1e9))
