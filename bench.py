@@ -63,6 +63,9 @@ def parse():
                     help="third leg: step = relax / (2 N), an over-relaxed majorisation step")
     ap.add_argument("--relax-momentum", type=float, default=0.4,
                     help="heavy-ball coefficient of the third leg")
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="untimed iterations run for this long right before the W warm-up "
+                         "steps, so that the timed block sees settled clocks (0 = none)")
     ap.add_argument("--reps", type=int, default=5,
                     help="further repetitions of the --steps block after the timed one, for "
                          "the spread of ms_per_step (0 = none)")
@@ -271,12 +274,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Order of the measurements: the convergence legs and the read sweep run FIRST, the
-    # throughput block last.  After an idle spell (input generation, the CPU work above)
-    # the chip needs some tens of milliseconds of load before its clocks settle (DVFS,
-    # MI355X_MICROARCH.md "DVFS give-back"): a block timed right after idle runs 4-5 %
-    # slower than the same block a moment later (see ms_per_step_reps).  A fit() runs
-    # hundreds of iterations back to back, so the settled figure is the one that counts.
+    # Order of the measurements: the convergence legs and the read sweep run FIRST, then
+    # --settle-ms of untimed iterations, then the W warm-up steps and the timed block.
+    # After an idle spell (input generation, host-side set-up) the chip needs a while
+    # under load before its clocks settle (DVFS, MI355X_MICROARCH.md "DVFS give-back"): a
+    # block timed right after idle ran 4-19 % slower than the same block a moment later
+    # (ms_per_step_reps).  A fit() runs hundreds of iterations back to back, so the
+    # settled figure is the one that counts.
     # BASELINE metric, second half: wall-clock from a resident matrix and the
     # noisy start X0 to S_k / S_0 <= 1e-3 (the synthetic matrix has a zero-stress
     # solution).  Run a fixed number of steps, then read k* off the history.
@@ -309,6 +313,12 @@ def main():
     read_ms = eng.stream_read_ms(10) if a.dtype == "float32" else None
     eng.set_coords(x0)                       # the timed block starts where the legs did
     eng.set_momentum(0.0)
+    eng.set_timing(1)                        # creates the HIP events now (host work), ...
+    eng.set_timing(False)                    # ... not between the warm-up and the timed block
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < a.settle_ms:
+        steps(max(10, a.steps))              # untimed; speed does not depend on the state
+        eng.sync()                           # (tools/state_probe.py), clocks do on the load
     steps(a.warmup)
     fence()
     # HIP events on every 8th step of the timed region: three records cost ~10 us of

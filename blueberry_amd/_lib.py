@@ -92,6 +92,9 @@ SIGNATURES = {
     "bb_cm_normalize": (c_int, [c_void_p, c_i64, p_dbl, p_dbl]),
     "bb_cm_marginals": (c_int, [c_void_p, p_dbl]),
     "bb_cm_filter": (c_int, [c_void_p, c_dbl, p_i64, ctypes.POINTER(ctypes.c_uint8)]),
+    "bb_cm_symv": (c_int, [c_void_p, p_dbl, p_dbl]),
+    "bb_cm_eigenvector": (c_int, [c_void_p, p_dbl, p_dbl, c_dbl, c_i64, p_i64, p_dbl]),
+    "bb_cm_correlation": (c_int, [c_void_p, p_dbl]),
     "bb_solver_set_wish_from_cm": (c_int, [c_void_p, c_void_p, c_int, c_dbl]),
     "bb_contactmap_scatter": (c_int, [p_dbl, c_i64, c_i32, p_dbl, c_i64, c_int]),
     "bb_contactmap_normalize": (c_int, [p_dbl, c_i64, p_dbl, p_dbl, c_int]),

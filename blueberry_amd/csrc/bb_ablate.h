@@ -42,6 +42,11 @@ BB_ABL_FLAG(kF64Libm, true);
 #else
 BB_ABL_FLAG(kF64Libm, false);
 #endif
+#ifdef BB_ABL_F64_GENERIC    // fp64 2 x 512 units through the generic unit (DPP row reduction,
+BB_ABL_FLAG(kF64Generic, true);   // per-row stores) -- run it with BB_DEFER_ROWS=0
+#else
+BB_ABL_FLAG(kF64Generic, false);
+#endif
 #ifdef BB_WAVE_TRACE          // diagnostic build: per-wave time stamps (tools/wave_trace.py)
 BB_ABL_FLAG(kWaveTrace, true);
 #else

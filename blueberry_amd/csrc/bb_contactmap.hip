@@ -12,7 +12,10 @@
 // IEEE division; a column's marginal is the sum of its elements in row order, which is
 // the order numpy's `matrix.sum(axis=0)` adds a C-contiguous matrix in (checked bit for
 // bit in tests/test_oracle.py).
+#include <math.h>
+
 #include <algorithm>
+#include <vector>
 
 #include "bb_common.h"
 
@@ -169,6 +172,256 @@ __global__ __launch_bounds__(256) void gather_kernel(const double *__restrict__ 
     const int64_t oc = old_of_new[c];
     for (int64_t r = blockIdx.y; r < dn; r += gridDim.y)
         out[r * dn + c] = in[(int64_t)old_of_new[r] * d + oc];
+}
+
+// ---- eigenvector (datatypes.pyx:216-235): Lanczos on the resident matrix -----------
+// y = M x, one wave per matrix row (4 rows per workgroup): the row is read once, in
+// 512-byte wave loads with kSymvUnroll of them in flight; HBM-bound, 8 B per element.
+constexpr int kSymvUnroll = 8;
+__global__ __launch_bounds__(256) void symv_kernel(const double *__restrict__ m, int64_t d,
+                                                   const double *__restrict__ x,
+                                                   double *__restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= d) return;
+    const double *p = m + row * d;
+    double acc = 0.0;
+    int64_t c = lane;
+    for (; c + 64 * (kSymvUnroll - 1) < d; c += 64 * kSymvUnroll) {
+        double a[kSymvUnroll], b[kSymvUnroll];
+#pragma unroll
+        for (int q = 0; q < kSymvUnroll; ++q) {
+            a[q] = __builtin_nontemporal_load(p + c + 64 * q);
+            b[q] = x[c + 64 * q];
+        }
+#pragma unroll
+        for (int q = 0; q < kSymvUnroll; ++q) acc = fma(a[q], b[q], acc);
+    }
+    for (; c < d; c += 64) acc = fma(p[c], x[c], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) y[row] = acc;
+}
+
+// out[j] = V[j] . w for the basis vectors j < k (one workgroup each); fixed-order sums
+__global__ __launch_bounds__(256) void basis_dots_kernel(const double *__restrict__ V, int64_t d,
+                                                         const double *__restrict__ w,
+                                                         double *__restrict__ out) {
+    __shared__ double sh[256];
+    const double *v = V + (int64_t)blockIdx.x * d;
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < d; i += 256) a = fma(v[i], w[i], a);
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
+// w -= sum_{j<k} c[j] V[j]
+__global__ __launch_bounds__(256) void basis_subtract_kernel(const double *__restrict__ V, int64_t d,
+                                                             int k, const double *__restrict__ c,
+                                                             double *__restrict__ w) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= d) return;
+    double a = w[i];
+    for (int j = 0; j < k; ++j) a = fma(-c[j], V[(int64_t)j * d + i], a);
+    w[i] = a;
+}
+
+// out = scale * in
+__global__ __launch_bounds__(256) void scale_kernel(const double *__restrict__ in, double scale,
+                                                    double *__restrict__ out, int64_t d) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < d) out[i] = scale * in[i];
+}
+
+// u = sum_{j<k} y[j] V[j]   (the Ritz vector)
+__global__ __launch_bounds__(256) void basis_combine_kernel(const double *__restrict__ V, int64_t d,
+                                                            int k, const double *__restrict__ y,
+                                                            double *__restrict__ u) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= d) return;
+    double a = 0.0;
+    for (int j = 0; j < k; ++j) a = fma(y[j], V[(int64_t)j * d + i], a);
+    u[i] = a;
+}
+
+// Eigen-decomposition of a small symmetric matrix on the host (cyclic Jacobi): a (n x n,
+// row-major) -> eigenvalues on its diagonal, eigenvectors in the columns of z.
+void jacobi_eigh(std::vector<double> &a, std::vector<double> &z, int n) {
+    z.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) z[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) off += a[(size_t)p * n + q] * a[(size_t)p * n + q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = a[(size_t)p * n + q];
+                if (apq == 0.0) continue;
+                const double app = a[(size_t)p * n + p], aqq = a[(size_t)q * n + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = a[(size_t)k * n + p], akq = a[(size_t)k * n + q];
+                    a[(size_t)k * n + p] = c * akp - sn * akq;
+                    a[(size_t)k * n + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = a[(size_t)p * n + k], aqk = a[(size_t)q * n + k];
+                    a[(size_t)p * n + k] = c * apk - sn * aqk;
+                    a[(size_t)q * n + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double zkp = z[(size_t)k * n + p], zkq = z[(size_t)k * n + q];
+                    z[(size_t)k * n + p] = c * zkp - sn * zkq;
+                    z[(size_t)k * n + q] = sn * zkp + c * zkq;
+                }
+            }
+    }
+}
+
+// ---- correlation (datatypes.pyx:173-188: numpy.corrcoef(matrix)) ---------------------
+// corrcoef = centre every row, Gram matrix of the centred rows, scale by the diagonal.
+// The Gram matrix is the one dense contraction of this library (2 d^3 / 2 flops: 1.6e13 at
+// d = 25k) and the one place the matrix cores belong: v_mfma_f64_16x16x4_f64, fp64 in and
+// out, so the result is numpy's to rounding (1e-10 asserted; BLAS adds in another order).
+constexpr int kGT = 128;  // output tile edge per workgroup (4 waves x 64 x 64)
+constexpr int kGK = 16;   // K per LDS tile
+constexpr int kGS = 18;   // LDS row stride in doubles: makes the 16 x 4 operand reads of a
+                          // wave (lane = row + 16 k) hit 64 distinct banks (ds_read_b64)
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// xc (dp rows of ldx doubles, zero-padded) = m - row mean; one wave per row, two passes
+__global__ __launch_bounds__(256) void center_rows_kernel(const double *__restrict__ m, int64_t d,
+                                                          double *__restrict__ xc, int64_t ldx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= d) return;
+    const double *p = m + row * d;
+    double acc = 0.0;
+    for (int64_t c = lane; c < d; c += 64) acc += p[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    const double mean = acc / (double)d;
+    double *q = xc + row * ldx;
+    for (int64_t c = lane; c < d; c += 64) q[c] = p[c] - mean;
+}
+
+// g (dp x dp) upper tiles = xc xc^T.  Workgroup = one 128 x 128 tile, TI <= TJ; wave =
+// 64 x 64 = 4 x 4 MFMA tiles (128 accumulator VGPRs).  Both operands are rows of xc
+// (K contiguous): each K-tile of 16 is staged through LDS as [row][18], the next one is
+// already on its way from HBM into registers while this one is multiplied.
+__global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__ xc, int64_t ldx,
+                                                      double *__restrict__ g, int64_t dp) {
+    const int TI = blockIdx.y, TJ = blockIdx.x;
+    if (TI > TJ) return;
+    __shared__ __attribute__((aligned(16))) double As[kGT * kGS];
+    __shared__ __attribute__((aligned(16))) double Bs[kGT * kGS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int64_t i0 = (int64_t)TI * kGT, j0 = (int64_t)TJ * kGT;
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const int srow = tid >> 3, skc = (tid & 7) * 2;   // staging: row srow + 32 q, doubles skc, skc+1
+    double2 ra[4], rb[4];
+    auto gload = [&](int64_t k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ra[q] = *reinterpret_cast<const double2 *>(xc + (i0 + srow + 32 * q) * ldx + k0 + skc);
+            rb[q] = *reinterpret_cast<const double2 *>(xc + (j0 + srow + 32 * q) * ldx + k0 + skc);
+        }
+    };
+    gload(0);
+    const int orow = lane & 15, ok = lane >> 4;       // operand element of this lane
+    for (int64_t k0 = 0; k0 < ldx; k0 += kGK) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<double2 *>(As + (srow + 32 * q) * kGS + skc) = ra[q];
+            *reinterpret_cast<double2 *>(Bs + (srow + 32 * q) * kGS + skc) = rb[q];
+        }
+        __syncthreads();
+        if (k0 + kGK < ldx) gload(k0 + kGK);
+#pragma unroll
+        for (int kk = 0; kk < kGK / 4; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = As[(wr * 64 + 16 * t + orow) * kGS + kk * 4 + ok];
+                b[t] = Bs[(wc * 64 + 16 * t + orow) * kGS + kk * 4 + ok];
+            }
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // v_mfma_f64_16x16x4_f64 leaves D[g + 4 r][j] in register r of lane 16 g + j (the fp64
+    // form interleaves the rows over the lane groups; the fp32 forms hold D[4 g + r][j])
+    const int gq = lane >> 4, jj = lane & 15;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+            double *o = g + (i0 + wr * 64 + 16 * ta + gq) * dp + j0 + wc * 64 + 16 * tb + jj;
+            o[0] = acc[ta][tb].x;
+            o[4 * dp] = acc[ta][tb].y;
+            o[8 * dp] = acc[ta][tb].z;
+            o[12 * dp] = acc[ta][tb].w;
+        }
+}
+
+__global__ void gram_diag_kernel(const double *__restrict__ g, int64_t dp, int64_t d, double fact_inv,
+                                 double *__restrict__ stddev) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < d) stddev[i] = sqrt(g[i * dp + i] * fact_inv);
+}
+
+// m (d x d) = clip(((g * 1/(d-1)) / std_i) / std_j, -1, 1), upper tile pairs + mirror
+// (numpy.corrcoef's own order of operations)
+__global__ __launch_bounds__(kT * 8) void corr_finalize_kernel(const double *__restrict__ g, int64_t dp,
+                                                              const double *__restrict__ stddev,
+                                                              double fact_inv, double *__restrict__ m,
+                                                              int64_t d) {
+    __shared__ double tile[kT][kT + 1];
+    const int TJ = blockIdx.y, TK = blockIdx.x;
+    if (TJ > TK) return;
+    const int tx = threadIdx.x % kT, ty = threadIdx.x / kT;
+#pragma unroll
+    for (int q = 0; q < kT / 8; ++q) {
+        const int rr = ty + 8 * q;
+        const int64_t j = (int64_t)TJ * kT + rr, k = (int64_t)TK * kT + tx;
+        double v = 0.0;
+        if (j < d && k < d) {
+            // lower cells of a diagonal tile: take the symmetric upper one (only the upper
+            // 128-tiles of g were computed, and within them every cell)
+            const int64_t a = j <= k ? j : k, b = j <= k ? k : j;
+            v = g[a * dp + b] * fact_inv;
+            v = v / stddev[a];
+            v = v / stddev[b];
+            v = v > 1.0 ? 1.0 : (v < -1.0 ? -1.0 : v);     // NaN stays NaN, as numpy.clip
+            m[j * d + k] = v;
+        }
+        tile[rr][tx] = v;
+    }
+    __syncthreads();
+    if (TJ == TK) return;
+#pragma unroll
+    for (int q = 0; q < kT / 8; ++q) {
+        const int rr = ty + 8 * q;
+        const int64_t kk = (int64_t)TK * kT + rr, jj = (int64_t)TJ * kT + tx;
+        if (kk < d && jj < d) m[kk * d + jj] = tile[tx][rr];
+    }
 }
 
 int cm_check(const bb_cm *cm, const char *who) {
@@ -371,6 +624,203 @@ int bb_cm_filter(bb_cm *cm, double threshold, int64_t *d_new, uint8_t *keep_out)
     cm->m = out;
     cm->d = dn;
     if (d_new) *d_new = dn;
+    return BB_OK;
+}
+
+int bb_cm_symv(bb_cm *cm, const double *x, double *y) {
+    BB_TRY(cm_check(cm, "bb_cm_symv"));
+    BB_REQUIRE(x != nullptr && y != nullptr, "bb_cm_symv: NULL argument");
+    const int64_t d = cm->d;
+    bb::DevBuf dx, dy;
+    hipError_t e = dx.alloc((size_t)d * 8);
+    if (e == hipSuccess) e = dy.alloc((size_t)d * 8);
+    if (e != hipSuccess) return bb::fail(BB_ERR_NOMEM, std::string("bb_cm_symv: ") + hipGetErrorString(e));
+    e = hipMemcpyAsync(dx.p, x, (size_t)d * 8, hipMemcpyHostToDevice, cm->stream);
+    if (e == hipSuccess)
+        e = bb::launch(symv_kernel, dim3((unsigned)((d + 3) / 4)), dim3(256), 0, cm->stream,
+                       (const double *)cm->m, d, (const double *)dx.p, (double *)dy.p);
+    if (e == hipSuccess) e = hipStreamSynchronize(cm->stream);
+    if (e == hipSuccess) e = hipMemcpy(y, dy.p, (size_t)d * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return bb::fail(BB_ERR_HIP, std::string("bb_cm_symv: ") + hipGetErrorString(e));
+    return BB_OK;
+}
+
+// Restarted Lanczos with full re-orthogonalisation for the eigenpair of largest
+// magnitude -- the pair scipy.sparse.linalg.eigsh(matrix, k=1) returns (ARPACK's
+// default which='LM'), reference blueberry/datatypes.pyx:234.  Every matrix-vector
+// product is one sweep of the resident matrix (symv_kernel); the basis (<= kBasis
+// vectors of d doubles) stays on the device; only the scalars of the tridiagonal matrix
+// cross PCIe.  The sign of the vector is fixed: its largest-magnitude component is > 0.
+int bb_cm_eigenvector(bb_cm *cm, double *vec, double *eigenvalue, double tol, int64_t max_matvecs,
+                      int64_t *matvecs_used, double *residual) {
+    BB_TRY(cm_check(cm, "bb_cm_eigenvector"));
+    BB_REQUIRE(vec != nullptr, "bb_cm_eigenvector: vec is NULL");
+    BB_REQUIRE(tol >= 0.0 && max_matvecs >= 1, "bb_cm_eigenvector: bad tol / max_matvecs");
+    const int64_t d = cm->d;
+    constexpr int kBasis = 48;
+    const int m = (int)std::min<int64_t>(kBasis, d);
+    bb::DevBuf V, w, coef, yv;
+    hipError_t e = V.alloc((size_t)(m + 1) * d * 8);
+    if (e == hipSuccess) e = w.alloc((size_t)d * 8);
+    if (e == hipSuccess) e = coef.alloc((size_t)(m + 1) * 8);
+    if (e == hipSuccess) e = yv.alloc((size_t)(m + 1) * 8);
+    if (e != hipSuccess)
+        return bb::fail(BB_ERR_NOMEM, std::string("bb_cm_eigenvector: ") + hipGetErrorString(e));
+    hipStream_t st = cm->stream;
+    double *dV = (double *)V.p, *dw = (double *)w.p, *dc = (double *)coef.p, *dy = (double *)yv.p;
+    const dim3 gvec((unsigned)((d + 255) / 256)), b256(256);
+    // start vector: a fixed pseudo-random direction (no global RNG state is touched)
+    std::vector<double> host((size_t)d);
+    {
+        uint64_t sdt = 0x9E3779B97F4A7C15ull;
+        double nrm = 0.0;
+        for (int64_t i = 0; i < d; ++i) {
+            sdt = sdt * 6364136223846793005ull + 1442695040888963407ull;
+            host[(size_t)i] = (double)((sdt >> 11) & 0xFFFFFFFFull) / 4294967296.0 + 0.25;
+            nrm += host[(size_t)i] * host[(size_t)i];
+        }
+        nrm = 1.0 / sqrt(nrm);
+        for (auto &h : host) h *= nrm;
+    }
+    e = hipMemcpy(dV, host.data(), (size_t)d * 8, hipMemcpyHostToDevice);
+    int64_t used = 0;
+    double theta = 0.0, resid = 0.0;
+    std::vector<double> alpha, beta, T, Z, c((size_t)m + 1);
+    bool done = false;
+    while (e == hipSuccess && !done) {
+        alpha.clear();
+        beta.clear();
+        int k = 0;
+        for (; k < m && e == hipSuccess; ++k) {
+            // w = M v_k
+            e = bb::launch(symv_kernel, dim3((unsigned)((d + 3) / 4)), b256, 0, st,
+                           (const double *)cm->m, d, (const double *)(dV + (int64_t)k * d), dw);
+            ++used;
+            // coefficients against the whole basis (alpha_k is the last one), subtract, and
+            // once more for the rounding the first pass leaves (classical Gram-Schmidt x 2)
+            double a_k = 0.0;
+            for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
+                e = bb::launch(basis_dots_kernel, dim3((unsigned)(k + 1)), b256, 0, st,
+                               (const double *)dV, d, (const double *)dw, dc);
+                if (e == hipSuccess)
+                    e = bb::launch(basis_subtract_kernel, gvec, b256, 0, st, (const double *)dV, d,
+                                   k + 1, (const double *)dc, dw);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (e == hipSuccess)
+                    e = hipMemcpy(c.data(), dc, (size_t)(k + 1) * 8, hipMemcpyDeviceToHost);
+                a_k += c[(size_t)k];
+            }
+            if (e != hipSuccess) break;
+            alpha.push_back(a_k);
+            // beta_k = |w|
+            e = bb::launch(basis_dots_kernel, dim3(1), b256, 0, st, (const double *)dw, d,
+                           (const double *)dw, dc);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            double b2 = 0.0;
+            if (e == hipSuccess) e = hipMemcpy(&b2, dc, 8, hipMemcpyDeviceToHost);
+            const double b = sqrt(b2 > 0.0 ? b2 : 0.0);
+            beta.push_back(b);
+            const double scale_ref = fabs(a_k) + (k > 0 ? beta[(size_t)k - 1] : 0.0);
+            if (!(b > 1e-14 * (scale_ref > 0.0 ? scale_ref : 1.0)) || used >= max_matvecs) {
+                ++k;                       // invariant subspace reached (or out of budget)
+                break;
+            }
+            if (k + 1 <= m && e == hipSuccess)
+                e = bb::launch(scale_kernel, gvec, b256, 0, st, (const double *)dw, 1.0 / b,
+                               dV + (int64_t)(k + 1) * d, d);
+        }
+        if (e != hipSuccess) break;
+        const int n = (int)alpha.size();
+        T.assign((size_t)n * n, 0.0);
+        for (int i = 0; i < n; ++i) {
+            T[(size_t)i * n + i] = alpha[(size_t)i];
+            if (i + 1 < n) T[(size_t)i * n + i + 1] = T[(size_t)(i + 1) * n + i] = beta[(size_t)i];
+        }
+        jacobi_eigh(T, Z, n);
+        int best = 0;
+        for (int i = 1; i < n; ++i)
+            if (fabs(T[(size_t)i * n + i]) > fabs(T[(size_t)best * n + best])) best = i;
+        theta = T[(size_t)best * n + best];
+        std::vector<double> y((size_t)n);
+        for (int i = 0; i < n; ++i) y[(size_t)i] = Z[(size_t)i * n + best];
+        resid = fabs(beta[(size_t)n - 1] * y[(size_t)n - 1]);   // |M u - theta u| of the Ritz pair
+        // the Ritz vector becomes basis vector 0: the answer, or the restart vector
+        e = hipMemcpy(dy, y.data(), (size_t)n * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            e = bb::launch(basis_combine_kernel, gvec, b256, 0, st, (const double *)dV, d, n,
+                           (const double *)dy, dw);
+        if (e == hipSuccess)
+            e = bb::launch(basis_dots_kernel, dim3(1), b256, 0, st, (const double *)dw, d,
+                           (const double *)dw, dc);
+        double n2 = 1.0;
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipMemcpy(&n2, dc, 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            e = bb::launch(scale_kernel, gvec, b256, 0, st, (const double *)dw,
+                           n2 > 0.0 ? 1.0 / sqrt(n2) : 1.0, dV, d);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        done = resid <= tol * fabs(theta) || resid == 0.0 || used >= max_matvecs || n == (int)d;
+    }
+    if (e == hipSuccess) e = hipMemcpy(host.data(), dV, (size_t)d * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return bb::fail(BB_ERR_HIP, std::string("bb_cm_eigenvector: ") + hipGetErrorString(e));
+    // sign: the component of largest magnitude is positive (first one on ties)
+    int64_t big = 0;
+    for (int64_t i = 1; i < d; ++i)
+        if (fabs(host[(size_t)i]) > fabs(host[(size_t)big])) big = i;
+    const double sgn = host[(size_t)big] < 0.0 ? -1.0 : 1.0;
+    for (int64_t i = 0; i < d; ++i) vec[i] = sgn * host[(size_t)i];
+    if (eigenvalue) *eigenvalue = theta;
+    if (matvecs_used) *matvecs_used = used;
+    if (residual) *residual = resid;
+    return BB_OK;
+}
+
+int bb_cm_correlation(bb_cm *cm, double *tflops) {
+    BB_TRY(cm_check(cm, "bb_cm_correlation"));
+    const int64_t d = cm->d;
+    const int64_t dp = bb::round_up(d, kGT), ldx = bb::round_up(d, kGK);
+    bb::DevBuf xc, g, sd;
+    hipError_t e = xc.alloc((size_t)dp * ldx * 8);
+    if (e == hipSuccess) e = g.alloc((size_t)dp * dp * 8);
+    if (e == hipSuccess) e = sd.alloc((size_t)d * 8);
+    if (e != hipSuccess)
+        return bb::fail(BB_ERR_NOMEM, std::string("bb_cm_correlation: ") + hipGetErrorString(e));
+    hipStream_t st = cm->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const double fact_inv = 1.0 / (double)(d - 1);   // numpy: true_divide(1, N - ddof); d = 1 -> inf
+    e = hipMemsetAsync(xc.p, 0, (size_t)dp * ldx * 8, st);
+    if (e == hipSuccess)
+        e = bb::launch(center_rows_kernel, dim3((unsigned)((d + 3) / 4)), dim3(256), 0, st,
+                       (const double *)cm->m, d, (double *)xc.p, ldx);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, st);
+    const unsigned nt = (unsigned)(dp / kGT);
+    if (e == hipSuccess)
+        e = bb::launch(gram_kernel, dim3(nt, nt), dim3(256), 0, st, (const double *)xc.p, ldx,
+                       (double *)g.p, dp);
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess)
+        e = bb::launch(gram_diag_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st,
+                       (const double *)g.p, dp, d, fact_inv, (double *)sd.p);
+    if (e == hipSuccess) {
+        const unsigned ntf = (unsigned)((d + kT - 1) / kT);
+        e = bb::launch(corr_finalize_kernel, dim3(ntf, ntf), dim3(kT * 8), 0, st, (const double *)g.p,
+                       dp, (const double *)sd.p, fact_inv, cm->m, d);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && tflops) {
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, e0, e1);
+        // flops of the tiles that were computed: nt (nt + 1) / 2 tiles of 2 * 128 * 128 * ldx
+        *tflops = ms > 0.f ? (double)nt * (nt + 1) / 2 * 2.0 * kGT * kGT * (double)ldx / (ms * 1e-3) / 1e12
+                           : 0.0;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess)
+        return bb::fail(BB_ERR_HIP, std::string("bb_cm_correlation: ") + hipGetErrorString(e));
     return BB_OK;
 }
 

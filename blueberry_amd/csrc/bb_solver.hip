@@ -51,6 +51,7 @@ struct bb_solver {
     double *d_f64_tmp = nullptr;  // (n_pad,3) staging for coordinate I/O
     int64_t rowpart_elems = 0, colpart_elems = 0;
     int n_waves = 0, n_slots = 0;
+    int wpb = 4;                   // waves per workgroup of the sweep: 4, or 8 (paired, see kernel)
     int defer_cap_units = 0;       // fp32: units of row sums a wave can park in LDS (0 = none)
     int64_t defer_lds_bytes = 0;   // dynamic LDS per workgroup for that, 0 = per-unit stores
     unsigned defer_attr_done = 0;  // kernel variants whose dynamic-LDS ceiling was raised
@@ -149,7 +150,15 @@ int build_indices(bb_solver *s) {
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device);
     int64_t want = (int64_t)cus * waves_per_cu(s->n_local);
     int64_t nw = std::max<int64_t>(1, std::min<int64_t>(want, s->n_local));
-    nw = bb::round_up(nw, 4);
+    {
+        // 8 waves per CU: put the two waves of a SIMD into one workgroup so that they can
+        // keep each other's pace (stress_grad_kernel, WPB = 8).  BB_PAIR=0 turns it off.
+        const char *e = getenv("BB_PAIR");
+        const bool pair = !(e && atoi(e) == 0);
+        s->wpb = (pair && (s->dtype == BB_F32 || s->wide) && waves_per_cu(s->n_local) >= 8 && nw >= 8)
+                     ? 8 : 4;
+    }
+    nw = bb::round_up(nw, s->wpb);
     s->n_waves = (int)nw;
 
     if (s->n_local >= ((int64_t)1 << 31))
@@ -177,13 +186,15 @@ int build_indices(bb_solver *s) {
         // until it has finished reading (stress_grad_kernel, DEFER); cap is what the
         // workgroups sharing a CU can hold.  BB_DEFER_ROWS=0 turns it off.
         const char *e = getenv("BB_DEFER_ROWS");
-        const int64_t wgs_per_cu = std::max<int64_t>(1, (nw / 4 + cus - 1) / cus);
+        const int64_t wgs_per_cu = std::max<int64_t>(1, (nw / s->wpb + cus - 1) / cus);
         const int64_t budget = 156 * 1024 / wgs_per_cu;               // of the CU's 160 KiB
-        const int64_t cap = std::min<int64_t>(chunk_max, (budget / 4 - 16) / 48);
+        const int64_t cap = std::min<int64_t>(chunk_max, (budget / s->wpb - 16 - 8) / 48);
         const bool on = !(e && atoi(e) == 0);
-        if (s->dtype == BB_F32 && on && cap > 0) {
+        if ((s->dtype == BB_F32 || s->wide) && on && cap > 0) {
             s->defer_cap_units = (int)cap;
-            s->defer_lds_bytes = 4 * (cap * 48 + 16);
+            s->defer_lds_bytes = s->wpb * (cap * 48 + 16) + 32;   // + the 8 progress words
+        } else if (s->wpb == 8) {
+            s->defer_lds_bytes = s->wpb * 16 + 32;                // progress words only
         }
     }
     // column-partial slots: one per (wave, strip) intersection, in wave order
@@ -312,13 +323,14 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
     T *rowpart = (T *)s->d_part +
                  (s->u_begin - s->t_first * s->L.units_per_tile) * (3 * s->L.rows_per_unit);
     T *colpart = (T *)s->d_part + s->rowpart_elems;
-    const dim3 grid(s->n_waves / 4), block(256);
+    const dim3 grid(s->n_waves / s->wpb), block(64 * s->wpb);
     // fp32 with the whole chunk of row sums parked in LDS (s->defer_lds_bytes > 0), or the
     // per-unit store.  The dynamic-LDS ceiling of a kernel is raised once per instantiation.
-#define BB_LAUNCH2(NTV, OPV, DEF, LDS)                                                          \
+#define BB_LAUNCH3(NTV, OPV, DEF, LDS, WPBV)                                                    \
     do {                                                                                        \
-        auto kern = stress_grad_kernel<T, W, NTV, OPV, DEF>;                                    \
-        constexpr unsigned bit = 1u << ((NTV ? 2 : 0) + (OPV == kOpMatvec2 ? 1 : 0));          \
+        auto kern = stress_grad_kernel<T, W, NTV, OPV, DEF, WPBV>;                              \
+        constexpr unsigned bit =                                                                \
+            1u << ((WPBV == 8 ? 4 : 0) + (NTV ? 2 : 0) + (OPV == kOpMatvec2 ? 1 : 0));          \
         if ((LDS) > 0 && !(s->defer_attr_done & bit)) {                                        \
             BB_HIP_CHECK(hipFuncSetAttribute((const void *)kern,                                \
                                              hipFuncAttributeMaxDynamicSharedMemorySize,        \
@@ -329,10 +341,19 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
                                 s->d_udesc, s->chunk_q, s->chunk_r, s->d_wave_slot, rowpart,    \
                                 colpart, s->d_stresspart, s->defer_cap_units));                 \
     } while (0)
+#define BB_LAUNCH2(NTV, OPV, DEF, LDS)                                                          \
+    do {                                                                                        \
+        if ((sizeof(T) == 4 || W) && s->wpb == 8)                                               \
+            BB_LAUNCH3(NTV, OPV, DEF, LDS, ((sizeof(T) == 4 || W) ? 8 : 4));                    \
+        else                                                                                    \
+            BB_LAUNCH3(NTV, OPV, DEF, LDS, 4);                                                  \
+    } while (0)
 #define BB_LAUNCH(NTV, OPV)                                                                     \
     do {                                                                                        \
-        if (sizeof(T) == 4 && s->defer_lds_bytes > 0)                                           \
-            BB_LAUNCH2(NTV, OPV, (sizeof(T) == 4), s->defer_lds_bytes);                         \
+        if ((sizeof(T) == 4 || W) && s->defer_cap_units > 0)                                    \
+            BB_LAUNCH2(NTV, OPV, (sizeof(T) == 4 || W), s->defer_lds_bytes);                    \
+        else if ((sizeof(T) == 4 || W) && s->wpb == 8)                                          \
+            BB_LAUNCH2(NTV, OPV, false, s->defer_lds_bytes);                                    \
         else                                                                                    \
             BB_LAUNCH2(NTV, OPV, false, 0);                                                     \
     } while (0)
@@ -343,6 +364,7 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
     }
 #undef BB_LAUNCH
 #undef BB_LAUNCH2
+#undef BB_LAUNCH3
     return BB_OK;
 }
 

@@ -48,6 +48,13 @@ struct Traits<double> {
     static __device__ __forceinline__ double eps2() { return 1e-300; }
 };
 
+// Wish distances below this are stored as 0 = "no constraint" by every pack kernel: far
+// below the distance floor eps of SPEC 2.2 (1e-15 / 1e-150), and what lets the kernels
+// turn "delta > 0" into a 0/1 weight with one clamped multiply (delta * 2^100 resp.
+// 2^1000 saturates to 1 for every delta that survives the flush).
+template <typename T>
+__host__ __device__ constexpr double wish_floor() { return sizeof(T) == 4 ? 1e-30 : 1e-290; }
+
 // Shape of a unit (8 KiB = 8 wave-loads) and of a strip.  LPR 16-byte loads per lane
 // and matrix row, VW = 64 * VPL * LPR columns per strip, RPU = 8 / LPR matrix rows.
 //   fp32          4 rows x 512 columns: 8 pairs per lane and row, packed math
@@ -196,6 +203,26 @@ __device__ __forceinline__ void store_row3(__amdgpu_buffer_rsrc_t rsrc, unsigned
 //               kernel of classical-MDS / spectral initialisation
 enum { kOpStress = 0, kOpMatvec2 = 1 };
 
+// 1/sqrt(d2) and sqrt(d2) in fp64 from the v_rsq_f64 seed (relative error <= 2^-23) by ONE
+// third-order step: with e = 1 - d2 r0^2, r = r0 (1 - e)^(-1/2) = r0 (1 + e/2 + 3 e^2/8 + ...);
+// the term dropped is 5 e^3 / 16 < 1e-20, so both results are good to the last bit or two.
+// 6 instructions behind the seed (two Newton steps on r plus one on the root took 10).
+__device__ __forceinline__ void rsqrt_sqrt_f64(double d2, double &rinv, double &dist) {
+    const double r0 = __builtin_amdgcn_rsq(d2);
+    const double t = d2 * r0;                    // ~ sqrt(d2)
+    const double e = fma(-t, r0, 1.0);
+    const double q = e * fma(e, 0.375, 0.5);
+    rinv = fma(r0, q, r0);
+    dist = fma(t, q, t);
+}
+// 1.0 where delta > 0, else 0.0, in one instruction (see wish_floor)
+__device__ __forceinline__ double weight01_f64(double delta) {
+    double w;
+    const double big = 0x1p1000;
+    asm("v_mul_f64 %0, %1, %2 clamp" : "=v"(w) : "v"(delta), "v"(big));
+    return w;
+}
+
 // Pair math for one matrix row of a unit: VPL pairs per lane.
 template <typename T, int C, int OP>
 __device__ __forceinline__ void pair_step(const typename Traits<T>::Vec &drow, T xi, T yi, T zi,
@@ -210,23 +237,27 @@ __device__ __forceinline__ void pair_step(const typename Traits<T>::Vec &drow, T
     }
     const T dx = xi - xj[C][0], dy = yi - xj[C][1], dz = zi - xj[C][2];
     const T d2 = fma(dx, dx, fma(dy, dy, fma(dz, dz, Traits<T>::eps2())));  // SPEC 2.2
+    if constexpr (sizeof(T) == 8 && !abl::kF64Libm) {
+        // fp64 has no packed forms and its pair math alone is worth the HBM time of a
+        // unit, so every instruction counts: 25 + v_rsq per pair
+        T rinv, dist;
+        rsqrt_sqrt_f64(d2, rinv, dist);
+        const T res = (dist - delta) * weight01_f64(delta);   // (dist - delta) or 0
+        s = fma(res, res, s);
+        const T coef = res * rinv;  // (d - delta) / d ; the factor 2 is applied in the reduce
+        gx = fma(coef, dx, gx); gy = fma(coef, dy, gy); gz = fma(coef, dz, gz);
+        gc[C][0] = fma(-coef, dx, gc[C][0]);
+        gc[C][1] = fma(-coef, dy, gc[C][1]);
+        gc[C][2] = fma(-coef, dz, gc[C][2]);
+        return;
+    }
     T rinv, dist;
     if constexpr (sizeof(T) == 4) {
         rinv = __builtin_amdgcn_rsqf(d2);
         dist = d2 * rinv;
-    } else if constexpr (abl::kF64Libm) {
-        dist = sqrt(d2);
-        rinv = 1.0 / dist;
     } else {
-        // v_rsq_f64 seed, two Newton steps on 1/sqrt, one on sqrt: ~12 fp64 ops,
-        // both results within 1-2 ulp (the parity tolerance is 1e-12)
-        T r = __builtin_amdgcn_rsq(d2);
-        const T h = T(0.5) * d2;
-        r = r * fma(-h * r, r, T(1.5));
-        r = r * fma(-h * r, r, T(1.5));
-        dist = d2 * r;
-        dist = fma(T(0.5) * r, fma(-dist, dist, d2), dist);
-        rinv = r;
+        dist = sqrt(d2);            // timing experiment (BB_ABL_F64_LIBM): ~55 fp64 ops
+        rinv = 1.0 / dist;
     }
     const T res = delta > T(0) ? dist - delta : T(0);
     s = fma(res, res, s);
@@ -295,6 +326,72 @@ __device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[8], co
         __builtin_amdgcn_sched_barrier(0);
     }
     stress += (double)s;
+}
+
+// ---- fp64, 2 x 512 units: the row sums go through the matrix pipe ---------------
+// In fp64 the pair math alone (~35 ops per pair, no packed forms) is worth the whole HBM
+// time of a unit, so everything else the VALU does is paid in full.  The largest such
+// item was the cross-lane reduction of the 6 row sums of a unit: v_add_f64 has no DPP
+// form, so each of the 6 tree steps of each sum is 2 v_mov_dpp + 1 add -- 108
+// instructions per unit, a sixth of the unit.  v_mfma_f64_16x16x4_f64 adds across lanes
+// for free: with A = one partial sum per lane (A[i][k] = lane i + 16 k) and B = a 0/1
+// selector with ones in column v, D[i][v] += sum_k A[i][k], and six of them accumulate the
+// unit's six sums side by side in the columns 0..5 of ONE 16 x 16 accumulator.  What is
+// left for the VALU: 3 adds over the lane's 4 accumulator rows and 2 lane-preserving
+// shuffles over the 4 lane groups.  The matrix pipe is idle otherwise and runs beside the
+// partner wave's VALU work; the order of the additions is fixed (bitwise reproducible).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// t + (t of the lane 16 / 32 further on or back): x = {r0, r0, r2, r2}, y = {r1, r1, r3, r3}
+__device__ __forceinline__ double swap_sum16(double t) {
+    const unsigned lo = (unsigned)__double2loint(t), hi = (unsigned)__double2hiint(t);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+__device__ __forceinline__ double swap_sum32(double t) {
+    const unsigned lo = (unsigned)__double2loint(t), hi = (unsigned)__double2hiint(t);
+    const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
+template <bool NT, int OP, bool DEFER, typename XR>
+__device__ __forceinline__ void process_unit_f64w(double2 (&d)[8], const XR &xrow,
+                                                  const double2 *__restrict__ next,
+                                                  const double (&xj)[4][2][3], double (&gc)[4][2][3],
+                                                  const double (&sel)[6], double &stress,
+                                                  __amdgpu_buffer_rsrc_t row_rsrc, unsigned row_voff,
+                                                  int stage_idx) {
+    extern __shared__ __attribute__((aligned(16))) float row_lds[];
+    double s = 0.0;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const double xi = xrow.get(3 * r), yi = xrow.get(3 * r + 1), zi = xrow.get(3 * r + 2);
+        double gx = 0.0, gy = 0.0, gz = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pair_step<double, 0, OP>(d[r * 4 + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
+            pair_step<double, 1, OP>(d[r * 4 + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
+            d[r * 4 + k] = stream_load<NT>(next + (r * 4 + k) * 64);
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(gx, sel[3 * r + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(gy, sel[3 * r + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(gz, sel[3 * r + 2], acc, 0, 0, 0);
+    }
+    // lane (g = lane / 16, j = lane % 16) holds four of the 16 rows of column j: add them,
+    // then the 4 lane groups with the gfx950 lane swaps (VALU, no LDS round trip):
+    // permlane16_swap exchanges the odd 16-lane rows of one register with the even rows
+    // of the other, permlane32_swap the upper half with the lower half
+    double t = (acc.x + acc.y) + (acc.z + acc.w);
+    t = swap_sum16(t);
+    t = swap_sum32(t);                   // every lane with lane % 16 == v: the unit's sum v
+    // lanes 48..53 keep one sum each; parked in LDS or stored, exactly one of the two lands
+    if constexpr (DEFER) *reinterpret_cast<double *>(row_lds + stage_idx) = t;
+    const u32x2 bits = {(unsigned)__double2loint(t), (unsigned)__double2hiint(t)};
+    __builtin_amdgcn_raw_buffer_store_b64(bits, row_rsrc, row_voff, 0, 0);
+    stress += s;
 }
 
 // ---- fp32: the same unit with explicit 2-wide packed math (v_pk_*_f32) -------
@@ -540,8 +637,18 @@ __device__ __forceinline__ void wave_stamp(double *stresspart, int n_waves, int 
 // share), they are parked there and written out as one contiguous burst when the
 // wave has finished reading: -5.8 % kernel time at N=50k.  A longer chunk parks its
 // LAST cap_units units and stores the ones before them directly.
-template <typename T, bool W, bool NT, int OP, bool DEFER>
-__global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
+//
+// WPB = waves per workgroup.  4: one wave per SIMD and workgroup.  8 (used when a CU
+// holds 8 waves): the two waves that share a SIMD -- wave k and k + 4 -- sit in ONE
+// workgroup and keep each other's pace.  Left alone, the SIMD's issue arbitration favours
+// the older of two co-resident waves on every conflict, and with static, equal chunks
+// that adds up: per-wave time stamps (tools/wave_trace.py) have the favoured partner
+// finish its chunk 15-25 % before the other, which then runs the tail alone with half the
+// bytes in flight.  Each wave posts the number of units it has done in LDS and reads its
+// partner's; whoever is behind raises its priority (s_setprio) for the next unit.  The
+// results do not depend on any of it: chunks, slots and summation order stay static.
+template <typename T, bool W, bool NT, int OP, bool DEFER, int WPB>
+__global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
     const T *__restrict__ units, const T *__restrict__ X, const int2 *__restrict__ udesc,
     int chunk_q, int chunk_r, const int32_t *__restrict__ wave_slot, T *__restrict__ rowpart,
     T *__restrict__ colpart, double *__restrict__ stresspart, int cap_units) {
@@ -549,19 +656,27 @@ __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
     constexpr int VPL = Traits<T>::VPL;
     constexpr int VW = Lay<T, W>::VW;
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave in workgroup
+    const int w = blockIdx.x * WPB + wib;
     // wave w owns units [w*q + min(w, r), +q (+1 if w < r)): arithmetic, not a table --
     // one dependent memory round trip less before the wave's first matrix load
     const int ua = w * chunk_q + (w < chunk_r ? w : chunk_r);
     const int ub = ua + chunk_q + (w < chunk_r ? 1 : 0);
-    const int n_waves_all = gridDim.x * 4;
+    const int n_waves_all = gridDim.x * WPB;
     wave_stamp(stresspart, n_waves_all, w, 0);      // (diagnostic build only)
     wave_stamp(stresspart, n_waves_all, w, 4);
     double stress = 0.0;
     // DEFER: this wave's parking space, cap_units * 12 floats + 4 dummy words
     extern __shared__ __attribute__((aligned(16))) float row_lds[];
-    const int stage0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (cap_units * 12 + 4);
+    const int stage0 = wib * (cap_units * 12 + 4);
+    // WPB = 8: progress words of the 8 waves, behind the parking spaces
+    int *progress = reinterpret_cast<int *>(row_lds + WPB * (cap_units * 12 + 4));
+    int partner_done = 0;
     const int park_from = (ub - ua) > cap_units ? (ub - ua) - cap_units : 0;
+    // fp64 2 x 512 units: column selectors of the MFMA row reduction (process_unit_f64w)
+    double sel[6];
+#pragma unroll
+    for (int v = 0; v < 6; ++v) sel[v] = (lane & 15) == v ? 1.0 : 0.0;
 
     if (ua < ub) {
         int slot = wave_slot[w];
@@ -630,6 +745,18 @@ __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
             0x00020000);
 
         auto unit_step = [&](int u) __attribute__((always_inline)) {
+            if constexpr (WPB == 8) {
+                // pace keeping (see the kernel's comment): the partner's count was read
+                // one unit ago, so nothing here waits on LDS
+                const int mine = u - ua;
+                if (__builtin_amdgcn_readfirstlane(partner_done) > mine)
+                    __builtin_amdgcn_s_setprio(1);
+                else
+                    __builtin_amdgcn_s_setprio(0);
+                __hip_atomic_store(progress + wib, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                partner_done = __hip_atomic_load(progress + (wib ^ 4), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             // the wave's last unit "prefetches" itself: harmless, stays in bounds
             const int un = u + 1 < ub ? u + 1 : u;
             const XRow xrn = xrow_load(dn.x);
@@ -647,7 +774,17 @@ __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
                                              : kDropOffset;
                 stage_slot = stage0 + ((mine && parked) ? (k - park_from) * 12 + (lane - 48)
                                                         : cap_units * 12 + (lane & 3));
-            } else {                        // fp64: lane 63 stores each row's three sums
+            } else if constexpr (W && !abl::kF64Generic) {
+                // fp64, 2 x 512 units: lanes 48..53 hold one of the unit's 6 sums each
+                // (parking as in fp32; an LDS slot is 4 bytes, a sum takes two)
+                const int k = u - ua;
+                const bool parked = DEFER && k >= park_from;
+                const bool mine = lane >= 48 && lane < 54;
+                row_voff = (mine && !parked) ? (unsigned)k * kRowBytes + (unsigned)(lane - 48) * 8u
+                                             : kDropOffset;
+                stage_slot = stage0 + ((mine && parked) ? (k - park_from) * 12 + (lane - 48) * 2
+                                                        : cap_units * 12 + 2 * (lane & 1));
+            } else {                        // fp64, 8 x 128: lane 63 stores each row's three sums
                 row_voff = lane == 63 ? (unsigned)(u - ua) * kRowBytes : kDropOffset;
             }
             if constexpr (sizeof(T) == 4) {
@@ -657,6 +794,9 @@ __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
                 process_unit_f32<NT, OP, DEFER>(d, xs12, unit_ptr<T>(units, un, lane), st, stress,
                                                 row_rsrc, row_voff, stage_slot);
             }
+            else if constexpr (W && !abl::kF64Generic)
+                process_unit_f64w<NT, OP, DEFER>(d, xr, unit_ptr<T>(units, un, lane), st.xj, st.gc,
+                                                 sel, stress, row_rsrc, row_voff, stage_slot);
             else
                 process_unit<T, W, NT, OP>(d, xr, unit_ptr<T>(units, un, lane), st.xj, st.gc, stress,
                                        row_rsrc, row_voff);
@@ -686,15 +826,22 @@ __global__ __launch_bounds__(256, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
             ++slot;
             if (u >= ub) break;
         }
+        if constexpr (WPB == 8) {
+            // done: the partner stops yielding
+            __hip_atomic_store(progress + wib, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_s_setprio(0);
+        }
         wave_stamp(stresspart, n_waves_all, w, 2);                    // last unit consumed
-        if constexpr (DEFER && sizeof(T) == 4) {
-            // the chunk's row sums, (ub - ua) * 12 floats, in one contiguous burst.
+        if constexpr (DEFER) {
+            // the chunk's row sums, 48 bytes per unit in either precision (12 floats or
+            // 6 doubles), in one contiguous burst.
             // Lanes read what other lanes of this wave parked: LDS operations of one
             // wave execute in program order; the fence is for the compiler.
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const int n4 = ((ub - ua) - park_from) * 3;   // float4 count
-            float4 *dst = reinterpret_cast<float4 *>(rowpart + ((int64_t)ua + park_from) * 12);
+            float4 *dst = reinterpret_cast<float4 *>(rowpart + ((int64_t)ua + park_from) *
+                                                                   (3 * Lay<T, W>::RPU));
             for (int q = lane; q < n4; q += 64) {
                 const float *src = row_lds + stage0 + 4 * q;
                 dst[q] = make_float4(src[0], src[1], src[2], src[3]);
@@ -1002,7 +1149,7 @@ __global__ __launch_bounds__(256) void convert_units_kernel(
         }
         // fp32: the kernel's 0/1 weight needs delta >= 2^-100; anything that small
         // is below the distance clamp eps = 1e-15 anyway and is stored as "none"
-        if (sizeof(T) == 4 && v < 1e-30) v = 0.0;
+        if (v < wish_floor<T>()) v = 0.0;
         out[e] = (T)v;
     }
 }
@@ -1030,7 +1177,7 @@ __global__ __launch_bounds__(256) void pack_units_from_matrix_kernel(
             else if (kind == BB_KIND_COUNTS)
                 v = pow(v, neg_inv_alpha);
         }
-        if (sizeof(T) == 4 && v < 1e-30) v = 0.0;
+        if (v < wish_floor<T>()) v = 0.0;
         out[e] = (T)v;
     }
 }
@@ -1085,7 +1232,7 @@ __global__ __launch_bounds__(256) void scatter_entries_kernel(
         v = 0.0;
     else if (kind == BB_KIND_COUNTS)
         v = pow(v, neg_inv_alpha);
-    if (sizeof(T) == 4 && v < 1e-30) v = 0.0;
+    if (v < wish_floor<T>()) v = 0.0;
     *cell = (T)v;
 }
 
@@ -1109,7 +1256,7 @@ __global__ __launch_bounds__(256) void gen_units_kernel(const double *__restrict
                          dz = xs[3 * i + 2] - xs[3 * j + 2];
             v = sqrt(dx * dx + dy * dy + dz * dz);
         }
-        if (sizeof(T) == 4 && v < 1e-30) v = 0.0;
+        if (v < wish_floor<T>()) v = 0.0;
         out[e] = (T)v;
     }
 }
@@ -1142,15 +1289,13 @@ __device__ __forceinline__ void pair_row(T delta, T xi, T yi, T zi, T xj, T yj, 
         rinv = __builtin_amdgcn_rsqf(d2);
         dist = d2 * rinv;
     } else {
-        T r = __builtin_amdgcn_rsq(d2);      // as pair_step<double>
-        const T h = T(0.5) * d2;
-        r = r * fma(-h * r, r, T(1.5));
-        r = r * fma(-h * r, r, T(1.5));
-        dist = d2 * r;
-        dist = fma(T(0.5) * r, fma(-dist, dist, d2), dist);
-        rinv = r;
+        rsqrt_sqrt_f64(d2, rinv, dist);      // as pair_step<double>
     }
-    const T res = delta > T(0) ? dist - delta : T(0);
+    T res;
+    if constexpr (sizeof(T) == 4)
+        res = delta > T(0) ? dist - delta : T(0);
+    else
+        res = (dist - delta) * weight01_f64(delta);
     s = fma(res, res, s);
     const T coef = res * rinv;
     gx = fma(coef, dx, gx);

@@ -334,8 +334,15 @@ class ContactMap(object):
                    "bb_cm_normalize")
 
     def correlation(self):
-        """Convert the map to a correlation map, in place (pyx:173-188)."""
-        self.matrix = numpy.corrcoef(self.matrix)
+        """Convert the map to a correlation map, in place (pyx:173-188:
+        `numpy.corrcoef(matrix)`), on the resident matrix: rows centred, Gram matrix on
+        the fp64 matrix cores, scaled by the diagonal and clipped to [-1, 1] in numpy's
+        order of operations (`bb_cm_correlation`).  Equal to numpy to rounding.
+        `correlation_tflops_` holds the rate of the Gram kernel afterwards."""
+        dev = self._resident()
+        tf = _lib.c_dbl()
+        _lib.check(dev._lib.bb_cm_correlation(dev._h, tf), "bb_cm_correlation")
+        self.correlation_tflops_ = float(tf.value)
 
     def plot(self, arcsinh=True, **kwargs):
         """Plot the contact map onto the current palette (pyx:190-214)."""
@@ -349,11 +356,24 @@ class ContactMap(object):
         m = self.to_host()
         plt.imshow(numpy.arcsinh(m) if arcsinh else m, **kwargs)
 
-    def eigenvector(self):
-        """First eigenvector of the matrix (restarted Lanczos, pyx:216-235)."""
-        import scipy.sparse.linalg
-        _, eigenvectors = scipy.sparse.linalg.eigsh(self.to_host(), k=1)
-        return eigenvectors[:, 0]
+    def eigenvector(self, tol=1e-13, max_matvecs=2000):
+        """First eigenvector of the matrix (pyx:216-235).
+
+        The reference calls `scipy.sparse.linalg.eigsh(matrix, k=1)`: ARPACK's
+        restarted Lanczos for the eigenpair of largest magnitude.  Here the same
+        pair comes from a restarted Lanczos over the RESIDENT matrix (`bb_cm_eigenvector`:
+        one HBM sweep per matrix-vector product, basis on the device).  ARPACK's sign is
+        arbitrary; this one makes the largest-magnitude component positive.
+        `eigenvalue_` holds the eigenvalue afterwards."""
+        dev = self._resident()
+        d = dev.d
+        vec = numpy.empty(d, dtype=numpy.float64)
+        lam, used, res = _lib.c_dbl(), _lib.c_i64(), _lib.c_dbl()
+        _lib.check(dev._lib.bb_cm_eigenvector(dev._h, _lib.as_f64_ptr(vec), lam, float(tol),
+                                              int(max_matvecs), used, res), "bb_cm_eigenvector")
+        self.eigenvalue_, self.eigen_matvecs_, self.eigen_residual_ = (
+            float(lam.value), int(used.value), float(res.value))
+        return vec
 
 
 DATA_DIR = RAO + ("results/Rao-Cell2014/fixedWindowSize/fithic/afterICE/{2}/"

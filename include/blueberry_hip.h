@@ -303,6 +303,22 @@ BB_API int bb_cm_marginals(bb_cm *cm, double *sums);
  * resident matrix becomes (d_new, d_new); keep_out (d bytes, may be NULL) receives the
  * 0/1 mask over the OLD indices. */
 BB_API int bb_cm_filter(bb_cm *cm, double threshold, int64_t *d_new, uint8_t *keep_out);
+/* y = M x over the resident matrix (x, y: d doubles on the host): one HBM sweep. */
+BB_API int bb_cm_symv(bb_cm *cm, const double *x, double *y);
+/* ContactMap.eigenvector (pyx:216-235: scipy.sparse.linalg.eigsh(matrix, k=1), i.e.
+ * ARPACK's eigenpair of LARGEST MAGNITUDE): restarted Lanczos with full
+ * re-orthogonalisation over the resident matrix, one HBM sweep per matrix-vector
+ * product.  Stops when |M v - lambda v| <= tol * |lambda| or after max_matvecs products.
+ * vec: d doubles, unit length, largest-magnitude component positive (ARPACK's sign is
+ * arbitrary).  eigenvalue / matvecs_used / residual may be NULL. */
+BB_API int bb_cm_eigenvector(bb_cm *cm, double *vec, double *eigenvalue, double tol,
+                             int64_t max_matvecs, int64_t *matvecs_used, double *residual);
+/* ContactMap.correlation (pyx:173-188): matrix <- numpy.corrcoef(matrix), in place on the
+ * resident matrix: rows centred, Gram matrix on the fp64 matrix cores
+ * (v_mfma_f64_16x16x4_f64; the one dense contraction on this path), scaled and clipped
+ * in numpy's order of operations.  Equal to numpy to rounding (BLAS sums in another
+ * order).  tflops (may be NULL): rate of the Gram kernel alone, by HIP events. */
+BB_API int bb_cm_correlation(bb_cm *cm, double *tflops);
 /* Hand the resident matrix to a solver of n_bins = d bins on the same device, device
  * to device (same meaning of kind / alpha as bb_solver_set_wish_dense). */
 BB_API int bb_solver_set_wish_from_cm(bb_solver *s, const bb_cm *cm, int kind, double alpha);

@@ -63,6 +63,10 @@ def test_compute_fails_loudly_without_gpu():
     with pytest.raises(RuntimeError, match="HIP device"):
         cm.filter()                      # filter runs on the device too: no numpy stand-in
     with pytest.raises(RuntimeError, match="HIP device"):
+        cm.correlation()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        cm.eigenvector()
+    with pytest.raises(RuntimeError, match="HIP device"):
         bb.ContactMap.from_triples(numpy.array([[0.0, 5000.0, 3.0]]), 5000, 4)
     assert cm.matrix.shape == (3, 3)     # the host copy was never lost
     n = _lib.ctypes.c_int(5)
@@ -219,17 +223,6 @@ def test_contactmap_normalize_precheck_and_shapes():
         bb.ContactMap.from_matrix(numpy.ones((4, 4))).normalize()
     with pytest.raises(ValueError):
         bb.ContactMap.from_matrix(numpy.ones((3, 4)))
-
-
-def test_contactmap_correlation_and_eigenvector_host_paths():
-    rng = numpy.random.default_rng(0)
-    a = rng.random((12, 12))
-    cm = bb.ContactMap.from_matrix(a + a.T)
-    v = cm.eigenvector()
-    w, V = numpy.linalg.eigh(a + a.T)
-    assert abs(abs(v @ V[:, -1]) - 1) < 1e-8
-    assert cm.correlation() is None
-    assert numpy.allclose(cm.matrix, numpy.corrcoef(a + a.T))
 
 
 # ---- FithicContactMap (datatypes.pyx:274-388) against the real reference ----------

@@ -9,4 +9,5 @@ SRC="blueberry_amd/csrc/bb_api.cpp blueberry_amd/csrc/bb_comm.cpp blueberry_amd/
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden \
     -Wno-unused-value -Wno-unused-result -fno-slp-vectorize -Iinclude -Iblueberry_amd/csrc "$@" \
     -o blueberry_amd/libabl_$name.so $SRC -ldl
+echo "$*" > blueberry_amd/libabl_$name.flags
 echo "built blueberry_amd/libabl_$name.so ($*)"
