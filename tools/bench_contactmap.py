@@ -49,6 +49,16 @@ for n_bins in [int(a) for a in sys.argv[1:]] or [24926]:
     print("pack into the solver's units, device to device       %.2f ms  -> %.0f GB/s algorithmic (12 B per upper pair)"
           % (t * 1e3, pairs * 12 / t / 1e9))
     eng.close()
+    # eigenvector (Lanczos over the resident matrix) and correlation (fp64 MFMA Gram kernel)
+    t0 = time.perf_counter(); v = cm.eigenvector(); t = time.perf_counter() - t0
+    print("eigenvector: %d matrix-vector products, residual %.1e    %.1f ms  -> %.0f GB/s over the products (8 B per element each)"
+          % (cm.eigen_matvecs_, cm.eigen_residual_, t * 1e3, cm.eigen_matvecs_ * d * d * 8 / t / 1e9))
+    cc = bb.ContactMap.from_matrix(numpy.zeros((1, 1)))      # a copy to turn into its correlation
+    cc._host, cc._dev, cc.n_bins = None, type(cm._resident()).from_host(cm.to_host(), 0), n_bins
+    t0 = time.perf_counter(); cc.correlation(); t = time.perf_counter() - t0
+    print("correlation: Gram kernel %.1f TFLOP/s fp64 (%.0f %% of the 78.6 TFLOP/s matrix peak), whole call %.1f ms"
+          % (cc.correlation_tflops_, cc.correlation_tflops_ / 78.6 * 100, t * 1e3))
+    del cc
     t0 = time.perf_counter(); cm.filter(float(numpy.median(cm.marginals()))); t = time.perf_counter() - t0
     dn = cm.shape[0]
     print("filter at the median marginal (-> %d bins)          %.2f ms  -> %.0f GB/s algorithmic"
