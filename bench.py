@@ -17,6 +17,10 @@ N GPUs split the SAME matrix (strong scaling): each rank owns a contiguous
 1/N of the packed units and the ranks exchange one all-reduce of the
 (3*n_pad+2)-element gradient buffer per step (RCCL over xGMI).
 
+Order of the measurements: convergence legs, read sweep, --settle-ms of untimed iterations
+(the chip's clocks need load to settle), W warm-up steps, the K timed
+steps (`value`, `ms_per_step`, `roofline`), then --reps more K-step blocks for the spread.
+
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel
 (stress_grad_kernel) by its ALGORITHMIC bytes -- 4 B (one fp32 wish distance)
 per pair-update, SURVEY.md 8(d) -- over its HIP-event duration measured on the
@@ -315,9 +319,23 @@ def main():
     eng.set_momentum(0.0)
     eng.set_timing(1)                        # creates the HIP events now (host work), ...
     eng.set_timing(False)                    # ... not between the warm-up and the timed block
+    # settle: the number of blocks is agreed between the ranks (every step of a multi-rank
+    # run is a collective: a loop that runs "for 300 ms" on each rank's own clock would
+    # leave the ranks with different step counts, i.e. inside different collectives)
+    blk = max(10, a.steps)
+    fence()
     t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < a.settle_ms:
-        steps(max(10, a.steps))              # untimed; speed does not depend on the state
+    steps(blk)
+    fence()
+    t_blk = time.perf_counter() - t_settle
+    if use_dist:
+        t = torch.tensor([t_blk], dtype=torch.float64,
+                         device="cuda" if a.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_blk = float(t.item())
+    n_settle = int(min(200, max(0, round(a.settle_ms * 1e-3 / max(t_blk, 1e-6)) - 1)))
+    for _ in range(n_settle if a.settle_ms > 0 else 0):
+        steps(blk)                           # untimed; speed does not depend on the state
         eng.sync()                           # (tools/state_probe.py), clocks do on the load
     steps(a.warmup)
     fence()
