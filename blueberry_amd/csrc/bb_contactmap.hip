@@ -315,14 +315,23 @@ __global__ __launch_bounds__(256) void center_rows_kernel(const double *__restri
 
 // g (dp x dp) upper tiles = xc xc^T.  Workgroup = one 128 x 128 tile, TI <= TJ; wave =
 // 64 x 64 = 4 x 4 MFMA tiles (128 accumulator VGPRs).  Both operands are rows of xc
-// (K contiguous): each K-tile of 16 is staged through LDS as [row][18], the next one is
-// already on its way from HBM into registers while this one is multiplied.
+// (K contiguous).  K-tiles of 16 go through LDS as [row][18], double-buffered: while
+// tile t is multiplied out of one buffer, tile t + 1 is on its way from HBM into
+// registers and is stored into the OTHER buffer afterwards -- one barrier per K-tile
+// (the second wave on each SIMD covers the operand reads' LDS latency; reading a step
+// ahead in registers spilled).
+// The tiles are walked in 8 x 8 patches (blockIdx -> patch, then row, column inside it), so
+// that the workgroups in flight at any time share both their row panels and their
+// column panels in L2 / the Infinity Cache instead of streaming a full panel per tile.
+constexpr int kGP = 8;   // patch edge, in tiles
 __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__ xc, int64_t ldx,
-                                                      double *__restrict__ g, int64_t dp) {
-    const int TI = blockIdx.y, TJ = blockIdx.x;
-    if (TI > TJ) return;
-    __shared__ __attribute__((aligned(16))) double As[kGT * kGS];
-    __shared__ __attribute__((aligned(16))) double Bs[kGT * kGS];
+                                                      double *__restrict__ g, int64_t dp, int nt) {
+    const int np = (nt + kGP - 1) / kGP;
+    const int patch = blockIdx.x / (kGP * kGP), inner = blockIdx.x % (kGP * kGP);
+    const int TI = (patch / np) * kGP + inner / kGP, TJ = (patch % np) * kGP + inner % kGP;
+    if (TI > TJ || TJ >= nt) return;
+    __shared__ __attribute__((aligned(16))) double As[2][kGT * kGS];
+    __shared__ __attribute__((aligned(16))) double Bs[2][kGT * kGS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = wv >> 1, wc = wv & 1;
     const int64_t i0 = (int64_t)TI * kGT, j0 = (int64_t)TJ * kGT;
@@ -332,31 +341,51 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
     const int srow = tid >> 3, skc = (tid & 7) * 2;   // staging: row srow + 32 q, doubles skc, skc+1
-    double2 ra[4], rb[4];
-    auto gload = [&](int64_t k0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ra[q] = *reinterpret_cast<const double2 *>(xc + (i0 + srow + 32 * q) * ldx + k0 + skc);
-            rb[q] = *reinterpret_cast<const double2 *>(xc + (j0 + srow + 32 * q) * ldx + k0 + skc);
-        }
-    };
-    gload(0);
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    f64x2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;       // the K-tile in flight, 128 B per thread
+    const double *ga = xc + (i0 + srow) * ldx + skc, *gb = xc + (j0 + srow) * ldx + skc;
+#define BB_GLOAD(k0)                                                           \
+    do {                                                                       \
+        ra0 = *reinterpret_cast<const f64x2 *>(ga + (k0));                     \
+        ra1 = *reinterpret_cast<const f64x2 *>(ga + 32 * ldx + (k0));          \
+        ra2 = *reinterpret_cast<const f64x2 *>(ga + 64 * ldx + (k0));          \
+        ra3 = *reinterpret_cast<const f64x2 *>(ga + 96 * ldx + (k0));          \
+        rb0 = *reinterpret_cast<const f64x2 *>(gb + (k0));                     \
+        rb1 = *reinterpret_cast<const f64x2 *>(gb + 32 * ldx + (k0));          \
+        rb2 = *reinterpret_cast<const f64x2 *>(gb + 64 * ldx + (k0));          \
+        rb3 = *reinterpret_cast<const f64x2 *>(gb + 96 * ldx + (k0));          \
+    } while (0)
+#define BB_LSTORE(buf)                                                         \
+    do {                                                                       \
+        double *sa = &As[buf][srow * kGS + skc], *sb = &Bs[buf][srow * kGS + skc]; \
+        *reinterpret_cast<f64x2 *>(sa) = ra0;                                  \
+        *reinterpret_cast<f64x2 *>(sa + 32 * kGS) = ra1;                       \
+        *reinterpret_cast<f64x2 *>(sa + 64 * kGS) = ra2;                       \
+        *reinterpret_cast<f64x2 *>(sa + 96 * kGS) = ra3;                       \
+        *reinterpret_cast<f64x2 *>(sb) = rb0;                                  \
+        *reinterpret_cast<f64x2 *>(sb + 32 * kGS) = rb1;                       \
+        *reinterpret_cast<f64x2 *>(sb + 64 * kGS) = rb2;                       \
+        *reinterpret_cast<f64x2 *>(sb + 96 * kGS) = rb3;                       \
+    } while (0)
     const int orow = lane & 15, ok = lane >> 4;       // operand element of this lane
-    for (int64_t k0 = 0; k0 < ldx; k0 += kGK) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<double2 *>(As + (srow + 32 * q) * kGS + skc) = ra[q];
-            *reinterpret_cast<double2 *>(Bs + (srow + 32 * q) * kGS + skc) = rb[q];
-        }
-        __syncthreads();
-        if (k0 + kGK < ldx) gload(k0 + kGK);
+    const double *pa = &As[0][(wr * 64 + orow) * kGS + ok];
+    const double *pb = &Bs[0][(wc * 64 + orow) * kGS + ok];
+    BB_GLOAD(0);
+    BB_LSTORE(0);
+    __syncthreads();
+    const int ntile = (int)(ldx / kGK);
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        // (the last trip re-reads its own tile into the idle buffer: no branch in the loop)
+        BB_GLOAD((int64_t)(t + 1 < ntile ? t + 1 : t) * kGK);
+        const double *qa = pa + buf * (kGT * kGS), *qb = pb + buf * (kGT * kGS);
 #pragma unroll
         for (int kk = 0; kk < kGK / 4; ++kk) {
             double a[4], b[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                a[t] = As[(wr * 64 + 16 * t + orow) * kGS + kk * 4 + ok];
-                b[t] = Bs[(wc * 64 + 16 * t + orow) * kGS + kk * 4 + ok];
+            for (int u = 0; u < 4; ++u) {
+                a[u] = qa[16 * u * kGS + kk * 4];
+                b[u] = qb[16 * u * kGS + kk * 4];
             }
 #pragma unroll
             for (int ta = 0; ta < 4; ++ta)
@@ -364,8 +393,11 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__
                 for (int tb = 0; tb < 4; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
         }
+        BB_LSTORE(buf ^ 1);
         __syncthreads();
     }
+#undef BB_GLOAD
+#undef BB_LSTORE
     // v_mfma_f64_16x16x4_f64 leaves D[g + 4 r][j] in register r of lane 16 g + j (the fp64
     // form interleaves the rows over the lane groups; the fp32 forms hold D[4 g + r][j])
     const int gq = lane >> 4, jj = lane & 15;
@@ -797,9 +829,10 @@ int bb_cm_correlation(bb_cm *cm, double *tflops) {
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) e = hipEventRecord(e0, st);
     const unsigned nt = (unsigned)(dp / kGT);
+    const unsigned np = (nt + kGP - 1) / kGP;
     if (e == hipSuccess)
-        e = bb::launch(gram_kernel, dim3(nt, nt), dim3(256), 0, st, (const double *)xc.p, ldx,
-                       (double *)g.p, dp);
+        e = bb::launch(gram_kernel, dim3(np * np * kGP * kGP), dim3(256), 0, st,
+                       (const double *)xc.p, ldx, (double *)g.p, dp, (int)nt);
     if (e == hipSuccess) e = hipEventRecord(e1, st);
     if (e == hipSuccess)
         e = bb::launch(gram_diag_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st,
