@@ -259,7 +259,7 @@ int build_indices(bb_solver *s) {
     BB_TRY(dev_alloc((char **)&s->d_part, part_total * es));
     BB_TRY(dev_alloc(&s->d_udesc, (int64_t)s->udesc.size()));
     BB_TRY(dev_alloc(&s->d_wave_slot, nw));
-    BB_TRY(dev_alloc(&s->d_stresspart, nw * 6));   // nw partials (+ 5 stamps per wave, diagnostic build)
+    BB_TRY(dev_alloc(&s->d_stresspart, nw * 9));   // nw partials (+ 8 stamps per wave, diagnostic build)
     BB_TRY(dev_alloc(&s->d_blk_ptr, nb + 1));
     BB_TRY(dev_alloc(&s->d_blk_chunk, (int64_t)fin_chunk.size()));
     BB_TRY(dev_alloc(&s->d_s1_ptr, (int64_t)s1_ptr.size()));
@@ -1461,15 +1461,16 @@ int bb_solver_measure_stream_read(bb_solver *s, int launches, double *ms_avg) {
 
 #ifdef BB_WAVE_TRACE
 // Diagnostic build only: the stamps of the last stress_grad_kernel launch,
-// 5 x uint64 per wave {start, first unit done, last unit consumed, end, xcc<<32 | hw_id}.
+// 8 x uint64 per wave {start, first unit done, last unit consumed, end, xcc<<32 | hw_id,
+// first load landed, window landed, coordinates landed}.
 BB_API int bb_solver_debug_wave_trace(bb_solver *s, unsigned long long *out, int64_t cap,
                                       int64_t *n_waves) {
     BB_REQUIRE(s != nullptr && n_waves != nullptr, "bb_solver_debug_wave_trace: NULL argument");
     BB_TRY(bb::enter_device(s->device));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     *n_waves = s->n_waves;
-    if (out && cap >= 5 * (int64_t)s->n_waves)
-        BB_HIP_CHECK(hipMemcpy(out, s->d_stresspart + s->n_waves, (size_t)s->n_waves * 40,
+    if (out && cap >= 8 * (int64_t)s->n_waves)
+        BB_HIP_CHECK(hipMemcpy(out, s->d_stresspart + s->n_waves, (size_t)s->n_waves * 64,
                                hipMemcpyDeviceToHost));
     return BB_OK;
 }

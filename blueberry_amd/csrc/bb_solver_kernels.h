@@ -592,7 +592,7 @@ __device__ __forceinline__ void store_strip(const T (&gc)[(Lay<T, W>::LPR)][Trai
     }
 }
 
-// Diagnostic build only (-DBB_WAVE_TRACE): time stamp k of wave w, 10-ns ticks of the
+// Diagnostic build only (-DBB_WAVE_TRACE): time stamp k (0..7) of wave w, 10-ns ticks of the
 // constant-rate clock, into a region of its own behind the per-wave stress partials
 // (nothing reads it but bb_solver_debug_wave_trace).  Folds away in the product build.
 __device__ __forceinline__ void wave_stamp(double *stresspart, int n_waves, int w, int k) {
@@ -606,7 +606,7 @@ __device__ __forceinline__ void wave_stamp(double *stresspart, int n_waves, int 
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
                 v = ((unsigned long long)xcc << 32) | hw;
             }
-            t[(long long)w * 5 + k] = v;
+            t[(long long)w * 8 + k] = v;
         }
     }
 }
@@ -738,6 +738,12 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
 #pragma unroll
             for (int r = 0; r < 8; ++r) d[r] = stream_load<NT>(first + r * 64);
         }
+        if constexpr (abl::kWaveTrace) {     // diagnostic build: when does the first data land?
+            asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            wave_stamp(stresspart, n_waves_all, w, 5);           // first 1 KiB of the window
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wave_stamp(stresspart, n_waves_all, w, 6);           // all 8 KiB of it
+        }
         // this wave's row partials: 3*RPU elements per unit of its group's chunk
         constexpr unsigned kRowBytes = 3 * Lay<T, W>::RPU * sizeof(T);
         const __amdgpu_buffer_rsrc_t row_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -815,6 +821,12 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
         for (;;) {
             const int curj = dc.y;
             strip_load(curj);
+            if constexpr (abl::kWaveTrace) {
+                if (u == ua) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    wave_stamp(stresspart, n_waves_all, w, 7);   // column + row coordinates here
+                }
+            }
             unit_step(u);
             if (u == ua) wave_stamp(stresspart, n_waves_all, w, 1);   // first unit done
             ++u;

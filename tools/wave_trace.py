@@ -3,7 +3,8 @@
     BB_LIB=$PWD/blueberry_amd/libabl_TRACE.so python tools/wave_trace.py [bins ...]
 
 libabl_TRACE.so = the product sources + -DBB_WAVE_TRACE (bb_ablate.h): every wave leaves
-five stamps (10-ns ticks): start, first unit done, last unit consumed, end, where it ran.
+eight stamps (10-ns ticks): start, first unit done, last unit consumed, end, where it ran,
+first load / whole window / coordinates landed.
 Prints, per problem size, for the LAST of a few warm launches: the launch's span, how far
 apart the waves start and finish, the prologue (start -> first unit done), the steady
 per-unit time, the epilogue, and the same per XCD."""
@@ -32,9 +33,9 @@ for n in sizes:
     tm = e.timing()
     nw = ctypes.c_int64()
     fn(e._h, None, 0, nw)
-    buf = numpy.zeros(5 * nw.value, dtype=numpy.uint64)
+    buf = numpy.zeros(8 * nw.value, dtype=numpy.uint64)
     _lib.check(fn(e._h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), buf.size, nw))
-    t = buf.reshape(-1, 5)
+    t = buf.reshape(-1, 8)
     lay = e.layout()
     units = (lay["u_end"] - lay["u_begin"]) / float(nw.value)
     t0 = t[:, 0].astype(numpy.int64); t1 = t[:, 1].astype(numpy.int64)
@@ -48,7 +49,12 @@ for n in sizes:
           % (n, nw.value, units, tm["grad_ms"] * 1e3))
     print("  launch span (first start -> last end)   %.2f us" % us(t3.max() - base))
     print("  wave start after the first start        " + q(t0 - base))
+    t5 = t[:, 5].astype(numpy.int64); t6 = t[:, 6].astype(numpy.int64); t7 = t[:, 7].astype(numpy.int64)
     print("  prologue: start -> first unit done      " + q(t1 - t0))
+    print("     start -> first 1 KiB of matrix here  " + q(t5 - t0))
+    print("     start -> whole 8-KiB window here     " + q(t6 - t0))
+    print("     start -> coordinates here            " + q(t7 - t0))
+    print("     coordinates here -> first unit done  " + q(t1 - t7))
     print("  steady: per unit after the first        " + q((t2 - t1) / max(units - 1, 1)))
     print("  epilogue: last unit consumed -> end     " + q(t3 - t2))
     print("  wave end after the first start          " + q(t3 - base))
@@ -58,6 +64,25 @@ for n in sizes:
         print("  xcd %d: %4d waves, ends med %.2f max %.2f us, per-unit med %.3f us"
               % (x, m.sum(), us(numpy.median(t3[m] - base)), us((t3[m] - base).max()),
                  us(numpy.median((t2[m] - t1[m]) / max(units - 1, 1)))))
+    # strip crossings per wave (a crossing = write the column partials, load the next
+    # strip's coordinates, drain the window): does a wave's end time follow them?
+    vw, upt = lay["vw"], lay["units_per_tile"]
+    ntile_b = lay["n_blocks"]
+    tile_J = numpy.concatenate([numpy.full(J + 1, J) for J in range(ntile_b)])
+    nloc = lay["u_end"] - lay["u_begin"]
+    q_, r_ = divmod(nloc, nw.value)
+    wv_ = numpy.arange(nw.value)
+    ua_ = wv_ * q_ + numpy.minimum(wv_, r_)
+    ub_ = ua_ + q_ + (wv_ < r_)
+    Ja = tile_J[(lay["u_begin"] + ua_) // upt]
+    Jb = tile_J[(lay["u_begin"] + ub_ - 1) // upt]
+    cross = Jb - Ja
+    dur = t3 - t0
+    for c in sorted(set(cross.tolist())):
+        m = cross == c
+        print("  waves crossing %d strip boundaries: %4d, duration med %.2f us (p10 %.2f, p90 %.2f), units %.1f"
+              % (c, m.sum(), us(numpy.median(dur[m])), us(numpy.percentile(dur[m], 10)),
+                 us(numpy.percentile(dur[m], 90)), float(numpy.mean((ub_ - ua_)[m]))))
     # who shares a SIMD with whom: HW_ID = wave_id[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]
     hw = (t[:, 4] & numpy.uint64(0xFFFFFFFF)).astype(numpy.int64)
     simd_key = (xcc << 16) | (hw & 0xFFF0)
