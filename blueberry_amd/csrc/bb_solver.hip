@@ -49,6 +49,7 @@ struct bb_solver {
     int64_t n_slices = 0, part2_off = 0;
     double *d_stress_hist = nullptr, *d_stress_scalar = nullptr;
     double *d_f64_tmp = nullptr;  // (n_pad,3) staging for coordinate I/O
+    void *d_mv_in = nullptr;      // (n_pad,3) right-hand sides of bb_solver_matvec_sq, kept
     int64_t rowpart_elems = 0, colpart_elems = 0;
     int n_waves = 0, n_slots = 0;
     int wpb = 4;                   // waves per workgroup of the sweep: 4, or 8 (paired, see kernel)
@@ -687,6 +688,7 @@ int bb_solver_destroy(bb_solver *s) {
     hipFree(s->d_stress_hist);
     hipFree(s->d_stress_scalar);
     hipFree(s->d_f64_tmp);
+    hipFree(s->d_mv_in);
     hipFree(s->d_full);
     hipFree(s->d_X2);
     hipFree(s->d_ro_part);
@@ -1305,8 +1307,9 @@ int bb_solver_matvec_sq(bb_solver *s, const double *x, double *y) {
         return bb::fail(BB_ERR_STATE, "bb_solver_matvec_sq: a bb_solver_grad is pending");
     BB_TRY(bb::enter_device(s->device));
     const int64_t n3 = s->L.n_pad * 3, es = bb::elem_size(s->dtype);
-    void *d_in = nullptr;
-    BB_TRY(dev_alloc((char **)&d_in, n3 * es));
+    // (a spectral start calls this ~40 times: the buffer is allocated once and kept)
+    if (!s->d_mv_in) BB_TRY(dev_alloc((char **)&s->d_mv_in, n3 * es));
+    void *d_in = s->d_mv_in;
     hipError_t e = hipMemsetAsync(s->d_f64_tmp, 0, (size_t)n3 * 8, s->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(s->d_f64_tmp, x, (size_t)s->L.n_bins * 24, hipMemcpyHostToDevice, s->stream);
@@ -1324,8 +1327,8 @@ int bb_solver_matvec_sq(bb_solver *s, const double *x, double *y) {
         if (e != hipSuccess)
             rc = bb::fail(BB_ERR_HIP, std::string("bb_solver_matvec_sq: ") + hipGetErrorString(e));
     }
-    hipStreamSynchronize(s->stream);
-    hipFree(d_in);
+    if (hipStreamSynchronize(s->stream) != hipSuccess && rc == BB_OK)
+        rc = bb::fail(BB_ERR_HIP, "bb_solver_matvec_sq: the stream did not drain");
     return rc;
 }
 

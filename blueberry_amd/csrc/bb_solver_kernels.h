@@ -1350,7 +1350,6 @@ __global__ __launch_bounds__(256) void row_owner_kernel(
     if (i < n) {
         xi = Xin[3 * (int64_t)i]; yi = Xin[3 * (int64_t)i + 1]; zi = Xin[3 * (int64_t)i + 2];
         const T *row = full + (int64_t)i * ld;
-#pragma unroll 4
         for (int c = part * kRowTrip; c < (int)ld; c += WPR * kRowTrip) {
 #pragma unroll
             for (int u = 0; u < kRowTrip / 64; ++u) {
