@@ -1,5 +1,6 @@
 /* examples/solve.c -- the C-ABI used from plain C (gcc, no HIP headers):
- * band count + a small solve, checked against closed forms.
+ * band count, a small solve, and the ContactMap stage on a resident matrix feeding a
+ * solver device to device -- each checked against closed forms.
  *
  *   gcc -std=c99 -Iinclude examples/solve.c -o /tmp/bb_solve \
  *       -Lblueberry_amd -lblueberry_hip -Wl,-rpath,$PWD/blueberry_amd -lm
@@ -60,6 +61,49 @@ int main(void) {
     for (int k = 1; k < K; k++)
         if (!(hist[k] < hist[k - 1])) return 3; /* lr = 1/2N is a majorisation step */
     if (!(hist[K - 1] < 1e-2 * hist[0])) return 4;
+
+    /* A1-A4 on one resident matrix: 6 bins, a dead bin (no contacts), scatter ->
+     * normalize (all KR = 2, expected = 1: every count / 4) -> filter -> solver */
+    {
+        enum { NBINS = 6, D = NBINS + 1, NT = 5 };
+        /* column-major (pos_i[], pos_j[], count[]), resolution 1000; bin 4 never occurs */
+        double tr[3 * NT] = {0, 0, 1000, 2000, 3000, /**/ 1000, 2000, 3000, 5000, 5000, /**/ 8, 4, 12, 16, 20};
+        double kr[NBINS] = {2, 2, 2, 2, 2, 2}, ke[NBINS] = {1, 1, 1, 1, 1, 1};
+        double m[D * D], marg[D];
+        unsigned char keep[D];
+        int64_t dn = 0;
+        bb_cm *cm = NULL;
+        CHECK(bb_cm_create(&cm, D, 0));
+        CHECK(bb_cm_scatter(cm, tr, NT, 1000));
+        CHECK(bb_cm_normalize(cm, NBINS, kr, ke));
+        CHECK(bb_cm_marginals(cm, marg));
+        if (marg[0] != 2 + 1 || marg[4] != 0 || marg[6] != 0) return 5;   /* 8/4 + 4/4; dead; pad */
+        CHECK(bb_cm_filter(cm, 0.0, &dn, keep));
+        if (dn != 5 || keep[4] || keep[6] || !keep[5]) return 6;
+        CHECK(bb_cm_download(cm, m, dn));
+        if (m[0 * dn + 1] != 2 || m[1 * dn + 0] != 2 || m[3 * dn + 4] != 5 || m[0] != 0) return 7;
+        double x5[15], h1[1];
+        for (int i = 0; i < 15; i++) x5[i] = (i * 7 % 5) * 0.3 + i * 0.01;
+        CHECK(bb_solver_create(&sol, dn, BB_F64, 0, 0, 1, NULL, NULL, 0));
+        CHECK(bb_solver_set_wish_from_cm(sol, cm, BB_KIND_COUNTS, 3.0));   /* device to device */
+        CHECK(bb_solver_set_coords(sol, x5));
+        CHECK(bb_solver_iterate(sol, 1, 0.05));
+        CHECK(bb_solver_get_stress_history(sol, h1, 1, &n_hist));
+        CHECK(bb_solver_destroy(sol));
+        CHECK(bb_cm_destroy(cm));
+        /* five constraints: (0,1) c=2, (0,2) c=1, (1,3) c=3, (2,4) c=4, (3,4) c=5; delta = c^(-1/3) */
+        const int pi[5] = {0, 0, 1, 2, 3}, pj[5] = {1, 2, 3, 4, 4};
+        const double pc[5] = {2, 1, 3, 4, 5};
+        double want = 0;
+        for (int q = 0; q < 5; q++) {
+            double dx = x5[3 * pi[q]] - x5[3 * pj[q]], dy = x5[3 * pi[q] + 1] - x5[3 * pj[q] + 1],
+                   dz = x5[3 * pi[q] + 2] - x5[3 * pj[q] + 2];
+            double r = sqrt(dx * dx + dy * dy + dz * dz) - pow(pc[q], -1.0 / 3.0);
+            want += r * r;
+        }
+        printf("resident ContactMap -> solver: stress %.12e (expect %.12e)\n", h1[0], want);
+        if (fabs(h1[0] - want) > 1e-12 * want) return 8;
+    }
     free(xs); free(x0); free(w);
     puts("C-ABI OK");
     return 0;

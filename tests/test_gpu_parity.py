@@ -276,6 +276,41 @@ def test_contactmap_correlation_vs_numpy(d):
         assert numpy.abs(got2[ok] - want2[ok]).max() < 1e-10
 
 
+def test_contactmap_handle_error_behaviour():
+    """The bb_cm_* entry points refuse bad calls with a status code and a message, as the
+    rest of the C-ABI does (no crash, no partial state)."""
+    import ctypes
+    lib = _lib.load()
+    h = _lib.c_void_p()
+    u8 = ctypes.POINTER(ctypes.c_uint8)
+    assert lib.bb_cm_create(h, 0, 0) == _lib.BB_ERR_INVALID                 # no bins
+    assert lib.bb_cm_create(h, 5, 99) == _lib.BB_ERR_INVALID                # no such device
+    assert b"device" in lib.bb_last_error()
+    assert lib.bb_cm_create(h, 5, 0) == _lib.BB_OK
+    kr = numpy.ones(4)
+    d = _lib.c_i64()
+    assert lib.bb_cm_normalize(h, 3, _lib.as_f64_ptr(kr), _lib.as_f64_ptr(kr)) == _lib.BB_ERR_INVALID
+    assert b"n_bins + 1" in lib.bb_last_error()                             # edge is 5, not 4
+    assert lib.bb_cm_normalize(h, 4, None, _lib.as_f64_ptr(kr)) == _lib.BB_ERR_INVALID
+    tr = numpy.array([0.0, 9000.0, 1.0])                                    # bin 9 of 5
+    assert lib.bb_cm_scatter(h, _lib.as_f64_ptr(tr), 1, 1000) == _lib.BB_ERR_INVALID
+    assert b"outside" in lib.bb_last_error()
+    m = numpy.full((5, 5), -1.0)
+    assert lib.bb_cm_download(h, _lib.as_f64_ptr(m), 5) == _lib.BB_OK
+    assert not m.any()                                                      # the map was cleared
+    assert lib.bb_cm_scatter(h, _lib.as_f64_ptr(tr), 1, 0) == _lib.BB_ERR_INVALID     # resolution 0
+    assert lib.bb_cm_upload(h, _lib.as_f64_ptr(m), 4) == _lib.BB_ERR_INVALID          # ld < d
+    assert lib.bb_cm_filter(h, 0.0, d, ctypes.cast(None, u8)) == _lib.BB_OK and d.value == 0
+    assert lib.bb_cm_dim(h, d) == _lib.BB_OK and d.value == 0               # nothing survives: 0 x 0
+    s = HipEngine(5, "float32")
+    assert lib.bb_solver_set_wish_from_cm(s._h, h, _lib.BB_KIND_WISH, 3.0) == _lib.BB_ERR_INVALID
+    assert b"edge" in lib.bb_last_error()                                   # 0 bins vs 5
+    s.close()
+    assert lib.bb_cm_destroy(h) == _lib.BB_OK
+    assert lib.bb_cm_dim(None, d) == _lib.BB_ERR_INVALID
+    assert lib.bb_cm_destroy(None) == _lib.BB_OK
+
+
 def test_contactmap_zero_kr_raises_like_reference():
     cm = bb.ContactMap.from_matrix(numpy.ones((4, 4)), KRnorm=numpy.array([1.0, 0.0, 1.0]),
                                    KRexpected=numpy.ones(3))
