@@ -1487,3 +1487,176 @@ int bb_solver_traffic(const bb_solver *s, int64_t *unit_bytes, int64_t *pairs_de
 }
 
 }  // extern "C"
+
+// ---- spectral start, device resident ---------------------------------------------
+namespace {
+
+// small dense helpers on the host (3 x 3, row-major)
+bool chol3_inv_upper(const double *g, double *rinv) {
+    // g = R^T R (R upper); returns R^-1 (upper).  False if g is not positive definite.
+    double r[9] = {0};
+    for (int j = 0; j < 3; ++j) {
+        double d = g[j * 3 + j];
+        for (int k = 0; k < j; ++k) d -= r[k * 3 + j] * r[k * 3 + j];
+        if (!(d > 0.0)) return false;
+        r[j * 3 + j] = sqrt(d);
+        for (int c = j + 1; c < 3; ++c) {
+            double v = g[j * 3 + c];
+            for (int k = 0; k < j; ++k) v -= r[k * 3 + j] * r[k * 3 + c];
+            r[j * 3 + c] = v / r[j * 3 + j];
+        }
+    }
+    for (int q = 0; q < 9; ++q) rinv[q] = 0.0;
+    for (int j = 0; j < 3; ++j) {
+        rinv[j * 3 + j] = 1.0 / r[j * 3 + j];
+        for (int i = j - 1; i >= 0; --i) {
+            double v = 0.0;
+            for (int k = i + 1; k <= j; ++k) v -= r[i * 3 + k] * rinv[k * 3 + j];
+            rinv[i * 3 + j] = v / r[i * 3 + i];
+        }
+    }
+    return true;
+}
+
+void jacobi3(double *a, double *z) {   // a symmetric 3 x 3 -> eigenvalues on its diagonal, vectors in z
+    for (int q = 0; q < 9; ++q) z[q] = (q % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 50; ++sweep) {
+        const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 3; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = a[p * 3 + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[q * 3 + q] - a[p * 3 + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = a[k * 3 + p], akq = a[k * 3 + q];
+                    a[k * 3 + p] = c * akp - sn * akq;
+                    a[k * 3 + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = a[p * 3 + k], aqk = a[q * 3 + k];
+                    a[p * 3 + k] = c * apk - sn * aqk;
+                    a[q * 3 + k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double zkp = z[k * 3 + p], zkq = z[k * 3 + q];
+                    z[k * 3 + p] = c * zkp - sn * zkq;
+                    z[k * 3 + q] = sn * zkp + c * zkq;
+                }
+            }
+    }
+}
+
+template <typename T>
+int spectral_init_t(bb_solver *s, int n_iter, const double *v0) {
+    const int64_t n = s->L.n_bins, n_pad = s->L.n_pad, n3 = n_pad * 3;
+    if (!s->d_mv_in) BB_TRY(dev_alloc((char **)&s->d_mv_in, n3 * (int64_t)sizeof(T)));
+    double *dV = nullptr, *dZ = nullptr, *dS = nullptr;     // V, Z: (n_pad,3) doubles; dS: 12 sums
+    bb::DevBuf bV, bZ, bS;
+    if (bV.alloc((size_t)n3 * 8) != hipSuccess || bZ.alloc((size_t)n3 * 8) != hipSuccess ||
+        bS.alloc(12 * 8) != hipSuccess)
+        return bb::fail(BB_ERR_NOMEM, "bb_solver_spectral_init: out of device memory");
+    dV = (double *)bV.p; dZ = (double *)bZ.p; dS = (double *)bS.p;
+    hipStream_t st = s->stream;
+    const dim3 gvec((unsigned)((n_pad + 255) / 256)), b256(256);
+    const Affine3 ident = {{0, 0, 0}, {1, 0, 0, 0, 1, 0, 0, 0, 1}, 1.0};
+    double sums[12];
+    auto fetch_sums = [&]() -> int {
+        BB_HIP_CHECK(hipStreamSynchronize(st));
+        BB_HIP_CHECK(hipMemcpy(sums, dS, sizeof(sums), hipMemcpyDeviceToHost));
+        return BB_OK;
+    };
+    // Z <- orthonormal basis of span(Z) by Cholesky-QR, twice (the second pass removes what
+    // the first leaves at cond(Z)^2 * eps); result in dV
+    auto orthonormalise = [&](double *src, double *dst) -> int {
+        double *a = src, *b = dst;
+        for (int pass = 0; pass < 2; ++pass) {
+            BB_HIP_CHECK(bb::launch(gram3_kernel<double, double>, dim3(1), dim3(1024), 0, st,
+                                    (const double *)a, (const double *)a, n, dS));
+            BB_TRY(fetch_sums());
+            Affine3 q = ident;
+            if (!chol3_inv_upper(sums, q.m))
+                return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: the iterate lost rank "
+                                              "(fewer than 3 independent directions in the map)");
+            BB_HIP_CHECK(bb::launch(affine3_kernel<double, double>, gvec, b256, 0, st,
+                                    (const double *)a, b, n, n_pad, q));
+            std::swap(a, b);
+        }
+        // two passes: the result is back in `src`; callers pass (dZ, dV) and read dZ... keep simple:
+        if (a != dst)
+            BB_HIP_CHECK(hipMemcpyAsync(dst, a, (size_t)n3 * 8, hipMemcpyDeviceToDevice, st));
+        return BB_OK;
+    };
+    // Z = -1/2 J (D o D) J V  (J = I - 11'/n): centre, sweep, centre
+    auto apply_B = [&](const double *V, double *Z) -> int {
+        BB_HIP_CHECK(bb::launch(gram3_kernel<double, double>, dim3(1), dim3(1024), 0, st, V, V, n, dS));
+        BB_TRY(fetch_sums());
+        Affine3 c = ident;
+        for (int k = 0; k < 3; ++k) c.mean[k] = sums[9 + k] / (double)n;
+        BB_HIP_CHECK(bb::launch(affine3_kernel<double, T>, gvec, b256, 0, st, V, (T *)s->d_mv_in, n,
+                                n_pad, c));
+        BB_TRY(launch_grad(s, kOpMatvec2, s->d_mv_in));
+        BB_TRY(launch_reduce(s, kReduceExchange, 0.0, nullptr, 1.0));
+        BB_HIP_CHECK(bb::launch(gram3_kernel<T, T>, dim3(1), dim3(1024), 0, st, (const T *)s->d_exch,
+                                (const T *)s->d_exch, n, dS));
+        BB_TRY(fetch_sums());
+        Affine3 w = ident;
+        for (int k = 0; k < 3; ++k) w.mean[k] = sums[9 + k] / (double)n;
+        w.scale = -0.5;
+        BB_HIP_CHECK(bb::launch(affine3_kernel<T, double>, gvec, b256, 0, st, (const T *)s->d_exch, Z,
+                                n, n_pad, w));
+        return BB_OK;
+    };
+    BB_HIP_CHECK(hipMemsetAsync(dZ, 0, (size_t)n3 * 8, st));
+    BB_HIP_CHECK(hipMemcpyAsync(dZ, v0, (size_t)n * 24, hipMemcpyHostToDevice, st));
+    BB_TRY(orthonormalise(dZ, dV));
+    for (int it = 0; it < n_iter; ++it) {
+        BB_TRY(apply_B(dV, dZ));
+        BB_TRY(orthonormalise(dZ, dV));
+    }
+    // Rayleigh-Ritz on span(V): M = sym(V^T B V), X0 = V E sqrt(max(lambda, 0))
+    BB_TRY(apply_B(dV, dZ));
+    BB_HIP_CHECK(bb::launch(gram3_kernel<double, double>, dim3(1), dim3(1024), 0, st, (const double *)dV,
+                            (const double *)dZ, n, dS));
+    BB_TRY(fetch_sums());
+    double m[9], z[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) m[i * 3 + j] = 0.5 * (sums[i * 3 + j] + sums[j * 3 + i]);
+    jacobi3(m, z);
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + 3, [&](int a, int b) { return m[a * 4] > m[b * 4]; });
+    Affine3 f = ident;
+    for (int c = 0; c < 3; ++c) {
+        const double lam = m[order[c] * 4] > 0.0 ? m[order[c] * 4] : 0.0;
+        for (int r = 0; r < 3; ++r) f.m[r * 3 + c] = z[r * 3 + order[c]] * sqrt(lam);
+    }
+    BB_HIP_CHECK(bb::launch(affine3_kernel<double, T>, gvec, b256, 0, st, (const double *)dV,
+                            (T *)s->d_X, n, n_pad, f));
+    BB_HIP_CHECK(hipMemsetAsync(s->d_V, 0, (size_t)n3 * sizeof(T), st));
+    BB_HIP_CHECK(hipStreamSynchronize(st));
+    return BB_OK;
+}
+
+}  // namespace
+
+extern "C" int bb_solver_spectral_init(bb_solver *s, int n_iter, const double *v0) {
+    BB_REQUIRE(s != nullptr && v0 != nullptr, "bb_solver_spectral_init: NULL argument");
+    BB_REQUIRE(n_iter >= 0 && n_iter <= 100000, "bb_solver_spectral_init: bad n_iter");
+    if (!s->have_wish) return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: no wish distances set");
+    if (s->world != 1)
+        return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: one rank only (with world > 1 the "
+                                      "caller sums bb_solver_matvec_sq over the ranks)");
+    if (s->grad_pending)
+        return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: a bb_solver_grad is pending");
+    BB_REQUIRE(s->L.n_bins >= 3, "bb_solver_spectral_init: needs at least 3 bins");
+    BB_TRY(bb::enter_device(s->device));
+    const int rc = s->dtype == BB_F32 ? spectral_init_t<float>(s, n_iter, v0)
+                                      : spectral_init_t<double>(s, n_iter, v0);
+    if (rc != BB_OK) return rc;
+    s->have_coords = true;
+    s->hist_n = 0;
+    s->grad_pending = false;
+    return BB_OK;
+}

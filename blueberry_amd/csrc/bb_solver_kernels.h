@@ -1438,6 +1438,64 @@ __global__ __launch_bounds__(256, 4) void stream_read_kernel(const float4 *__res
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[w] = acc.x;  // keep the loads alive
 }
 
+// --------------------------------------------------------------------------
+// spectral start on the device (bb_solver_spectral_init): the N x 3 side of the block
+// power iteration.  All of it is O(N): one workgroup, fixed-order sums.
+// --------------------------------------------------------------------------
+// out[0..8] = A^T B (3 x 3) and out[9..11] = column sums of A, over n rows of (n,3) arrays
+template <typename TA, typename TB>
+__global__ __launch_bounds__(1024) void gram3_kernel(const TA *__restrict__ A,
+                                                     const TB *__restrict__ B, int64_t n,
+                                                     double *__restrict__ out) {
+    __shared__ double sh[12][16];
+    double acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const double a0 = (double)A[3 * i], a1 = (double)A[3 * i + 1], a2 = (double)A[3 * i + 2];
+        const double b0 = (double)B[3 * i], b1 = (double)B[3 * i + 1], b2 = (double)B[3 * i + 2];
+        acc[0] = fma(a0, b0, acc[0]); acc[1] = fma(a0, b1, acc[1]); acc[2] = fma(a0, b2, acc[2]);
+        acc[3] = fma(a1, b0, acc[3]); acc[4] = fma(a1, b1, acc[4]); acc[5] = fma(a1, b2, acc[5]);
+        acc[6] = fma(a2, b0, acc[6]); acc[7] = fma(a2, b1, acc[7]); acc[8] = fma(a2, b2, acc[8]);
+        acc[9] += a0; acc[10] += a1; acc[11] += a2;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        double v = acc[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) sh[q][wv] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        double v = 0.0;
+        for (int k = 0; k < 16; ++k) v += sh[threadIdx.x][k];
+        out[threadIdx.x] = v;
+    }
+}
+
+// out_i = scale * ((in_i - mean) M), rows i < n_bins; M is 3 x 3 row-major; rows beyond
+// n_bins (padding) are written as 0.  The 12 numbers travel as kernel arguments.
+struct Affine3 {
+    double mean[3], m[9], scale;
+};
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void affine3_kernel(const TI *__restrict__ in, TO *__restrict__ out,
+                                                      int64_t n_bins, int64_t n_pad, Affine3 a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pad) return;
+    double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+    if (i < n_bins) {
+        const double x0 = (double)in[3 * i] - a.mean[0], x1 = (double)in[3 * i + 1] - a.mean[1],
+                     x2 = (double)in[3 * i + 2] - a.mean[2];
+        o0 = a.scale * (x0 * a.m[0] + x1 * a.m[3] + x2 * a.m[6]);
+        o1 = a.scale * (x0 * a.m[1] + x1 * a.m[4] + x2 * a.m[7]);
+        o2 = a.scale * (x0 * a.m[2] + x1 * a.m[5] + x2 * a.m[8]);
+    }
+    out[3 * i] = (TO)o0; out[3 * i + 1] = (TO)o1; out[3 * i + 2] = (TO)o2;
+}
+
 template <typename T>
 __global__ void f64_to_T_kernel(const double *__restrict__ in, T *__restrict__ out, int64_t n) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -137,6 +137,13 @@ class HipEngine(object):
                    "bb_solver_matvec_sq")
         return y
 
+    def spectral_init_device(self, n_iter, v0):
+        """Classical-MDS start computed and left on the device (one rank):
+        `bb_solver_spectral_init`.  v0: (n_bins, 3) start of the block power iteration."""
+        v0 = _check_coords(v0, self.n_bins)
+        _lib.check(self._lib.bb_solver_spectral_init(self._h, int(n_iter), _lib.as_f64_ptr(v0)),
+                   "bb_solver_spectral_init")
+
     def stress(self):
         out = _lib.c_dbl()
         _lib.check(self._lib.bb_solver_stress(self._h, out), "bb_solver_stress")
@@ -533,9 +540,14 @@ class StructureSolver(object):
                 eng.set_wish_sparse(rows, cols, vals, self.kind, self.alpha, KRnorm, KRexpected)
             else:
                 eng.set_wish_dense(matrix, self.kind, self.alpha)
-            if init is None:                       # 'spectral': needs the resident matrix
-                init = spectral_init(eng, n, world, seed=self.seed)
-            eng.set_coords(init)
+            if init is None and world == 1 and hasattr(eng, "spectral_init_device"):
+                # 'spectral' on one rank: the whole block power iteration stays on the device
+                v0 = numpy.random.default_rng(self.seed).standard_normal((n, 3))
+                eng.spectral_init_device(40, v0)
+            else:
+                if init is None:                   # 'spectral', several ranks / test engines
+                    init = spectral_init(eng, n, world, seed=self.seed)
+                eng.set_coords(init)
             if self.momentum:
                 eng.set_momentum(self.momentum)
             if world > 1:
@@ -598,6 +610,9 @@ def spectral_init(eng, n, world, n_iter=40, seed=0):
     """Classical-MDS start: the top three eigenpairs of B = -1/2 J (D o D) J,
     J = I - 11'/n, by block power iteration with a Rayleigh-Ritz step, using the
     device matvec over the resident units (`bb_solver_matvec_sq`); X0 = V sqrt(L).
+    This is the host-driven form (several ranks: the per-rank products are summed over
+    the ranks between steps; and engines without a device); on one rank
+    `HipEngine.spectral_init_device` runs the same iteration without leaving the device.
     Exact (up to a rigid motion) for a complete, noise-free distance matrix; for
     incomplete maps the missing pairs count as zero distance, so it is a start,
     not a solution.  Plays the part SURVEY.md 8(f)-2 assigns to the reference's

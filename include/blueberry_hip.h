@@ -236,6 +236,15 @@ BB_API int bb_solver_write_exchange(bb_solver *s, const double *host, int64_t n)
  * ContactMap.eigenvector (blueberry/datatypes.pyx:216-235). */
 BB_API int bb_solver_matvec_sq(bb_solver *s, const double *x, double *y);
 
+/* Classical-MDS start computed and LEFT on the device (one rank): `n_iter` block power
+ * iterations on B = -1/2 J (D o D) J over the resident units (one sweep each, as
+ * bb_solver_matvec_sq) from the (n_bins,3) host start `v0`, Cholesky-QR between them, a
+ * 3 x 3 Rayleigh-Ritz step, X0 = V sqrt(Lambda) written straight into the solver's
+ * coordinates (history and velocity reset, as bb_solver_set_coords).  Only 12 doubles per
+ * step cross PCIe.  The role SURVEY.md 8(f)-2 gives ContactMap.eigenvector as the solver's
+ * initialisation (blueberry/datatypes.pyx:216-235). */
+BB_API int bb_solver_spectral_init(bb_solver *s, int n_iter, const double *v0);
+
 /* Stress of the current coordinates (one gradient pass, no update). */
 BB_API int bb_solver_stress(bb_solver *s, double *stress);
 /* Copies the stress history (one value per completed iteration since the

@@ -897,6 +897,30 @@ def test_spectral_init_recovers_exact_distances():
     assert numpy.abs(d - w).max() < 1e-3 * w.max()
     with pytest.raises(ValueError):
         bb.StructureSolver(init="pca")
+    # the device-resident iteration (used above) and the host-driven one span the same
+    # subspace: same start-up stress to rounding, same pairwise distances
+    from blueberry_amd.solver import spectral_init
+    for dtype, tol in (("float64", 1e-9), ("float32", 1e-3)):
+        e = HipEngine(n, dtype)
+        e.set_wish_dense(w, "wish", 3.0)
+        x_host = spectral_init(e, n, 1, seed=0)
+        e.spectral_init_device(40, numpy.random.default_rng(0).standard_normal((n, 3)))
+        x_dev = e.get_coords()
+        assert e.stress_history().size == 0
+        d_host, d_dev = _oracle.wish_from_coords(x_host), _oracle.wish_from_coords(x_dev)
+        assert numpy.abs(d_dev - d_host).max() < tol * w.max(), dtype
+        assert numpy.abs(d_dev - w).max() < max(tol, 1e-6) * w.max(), dtype
+        e.iterate(2, 1.0 / (2 * n))
+        assert e.stress_history().shape == (2,)
+        e.close()
+    # an incomplete map (a third of the pairs missing) still gives a usable start
+    rng = numpy.random.default_rng(5)
+    hole = numpy.triu(rng.random((n, n)) < 0.33, 1)
+    wm = w.copy()
+    wm[hole | hole.T] = 0.0
+    sp = bb.StructureSolver(n_iter=30, dtype="float32", kind="wish", init="spectral").fit(wm)
+    rd = bb.StructureSolver(n_iter=30, dtype="float32", kind="wish", init="random").fit(wm)
+    assert numpy.isfinite(sp.structure_).all() and sp.stress_[-1] < rd.stress_[-1]
 
 
 # ---- BASELINE config 2 at its full size, directly against the oracle -----------------
