@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--settle-ms", type=float, default=300.0,
                     help="untimed iterations run for this long right before the W warm-up "
                          "steps, so that the timed block sees settled clocks (0 = none)")
+    ap.add_argument("--event-stride", type=int, default=8,
+                    help="HIP events around the kernels of every k-th timed step (0 = none: "
+                         "then roofline.kernel_ms is 0)")
     ap.add_argument("--reps", type=int, default=5,
                     help="further repetitions of the --steps block after the timed one, for "
                          "the spread of ms_per_step (0 = none)")
@@ -341,7 +344,7 @@ def main():
     fence()
     # HIP events on every 8th step of the timed region: three records cost ~10 us of
     # stream time, too much to put on every step once a step is ~0.1 ms (8 GPUs)
-    eng.set_timing(8 if a.steps >= 16 else 1)
+    eng.set_timing((a.event_stride if a.steps >= 16 else 1) if a.event_stride > 0 else 0)
     t0 = time.perf_counter()
     steps(a.steps)
     fence()
