@@ -461,4 +461,17 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # A rank that fails must END, at once: the launcher then stops the other ranks.  Left
+        # to the interpreter's shutdown it can sit in a communicator's destructor while its
+        # peers wait in a collective it will never join.
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            os._exit(1)
+        raise
