@@ -228,15 +228,27 @@ int build_indices(bb_solver *s) {
     for (int sl = 0; sl < s->n_slots; ++sl)
         blk_chunk[fill[slot_strip[sl]]++] = s->rowpart_elems + (int64_t)sl * ch;
 
-    // Two-stage reduce: a block's list can hold hundreds of chunks (one per strip
-    // of its tile row).  Lists longer than kSlice are cut into slices that stage 1
-    // sums in parallel into `part2`; the final stage then sums the slice results.
+    // Reduce: a block's list can hold hundreds of chunks (one per strip of its tile row, one
+    // per wave that crossed its strip).  One element per thread and kReduceSlice loads in
+    // flight make a list of L chunks cost about L / kReduceSlice memory round trips, so while
+    // the longest list has at most 128 chunks (N <= ~35k on one rank, every 1/8 share of
+    // N=50k) ONE launch sums every list whole; beyond that lists are cut into slices that a
+    // first launch sums in parallel into `part2`, which the final stage then combines.
+    // Measured (profiles/r02_reduce_ab.txt): one launch saves 1-1.6 us per iteration at
+    // N=17,700 / 24,926, nothing at 50k, and loses 1-2 us at 61,914 -- the reduce is bound by
+    // the 20-56 MB of partials the sweep has just written, not by its launches.
+    // BB_REDUCE_SINGLE_MAX overrides.
     constexpr int64_t kSlice = kReduceSlice;
+    int64_t single_max = 128;
+    if (const char *e = getenv("BB_REDUCE_SINGLE_MAX")) single_max = atoll(e);
+    int64_t longest = 0;
+    for (int64_t b = 0; b < nb; ++b) longest = std::max(longest, blk_ptr[b + 1] - blk_ptr[b]);
+    const int64_t slice_from = longest <= single_max ? longest : kSlice;   // lists longer than this are sliced
     std::vector<int64_t> s1_ptr(1, 0), s1_chunk, fin_ptr(nb + 1, 0), fin_chunk;
     s->part2_off = s->rowpart_elems + s->colpart_elems;
     for (int64_t b = 0; b < nb; ++b) {
         const int64_t k0 = blk_ptr[b], k1 = blk_ptr[b + 1];
-        if (k1 - k0 <= kSlice) {
+        if (k1 - k0 <= slice_from) {
             for (int64_t k = k0; k < k1; ++k) fin_chunk.push_back(blk_chunk[k]);
         } else {
             for (int64_t k = k0; k < k1; k += kSlice) {
