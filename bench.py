@@ -384,6 +384,7 @@ def main():
 
     hist = eng.stress_history()
     traffic = eng.traffic()
+    path, waves_per_row = eng.iteration_path()
     eng_comm = {"peer": "peer exchange (one-shot, in-kernel, IPC arenas over xGMI)",
                 "rccl": "library-owned RCCL communicator", "torch": "torch.distributed (RCCL)",
                 "host": "gloo, host-staged (rehearsal)", None: "none"}[eng._comm_state]
@@ -398,6 +399,11 @@ def main():
         # dominant kernel: algorithmic bytes this rank's launch streams / its duration
         alg_bytes = pairs * es / float(world)
         achieved = alg_bytes / (tim["grad_ms"] * 1e-3) / 1e9 if tim["grad_ms"] > 0 else 0.0
+        tname = "float" if es == 4 else "double"
+        kernel = ("stress_grad_kernel<%s>" % tname if path == "units" else
+                  "row_owner_kernel<%s, %d>: one launch per iteration over BOTH triangles, which "
+                  "stay in L2 / the Infinity Cache -- launch-bound, the HBM roofline does not apply"
+                  % (tname, waves_per_row))
         out = {
             "metric": "Gpair-updates/s per stress iteration, N=50k" if n == 50000 else
                       "Gpair-updates/s per stress iteration, N=%d" % n,
@@ -427,7 +433,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(n, a.dtype, world),
-                         "kernel": "stress_grad_kernel<%s>" % ("float" if es == 4 else "double"),
+                         "kernel": kernel,
                          "kernel_ms": tim["grad_ms"], "reduce_update_ms": tim["reduce_ms"],
                          # start-to-start of consecutive steps on the device: what is
                          # left after the two figures above is exchange + update + gaps

@@ -1491,6 +1491,13 @@ BB_API int bb_solver_debug_wave_trace(bb_solver *s, unsigned long long *out, int
 }
 #endif
 
+int bb_solver_iteration_path(const bb_solver *s, int *row_owner, int *waves_per_row) {
+    BB_REQUIRE(s != nullptr, "bb_solver_iteration_path: solver is NULL");
+    if (row_owner) *row_owner = s->row_owner ? 1 : 0;
+    if (waves_per_row) *waves_per_row = s->row_owner ? s->ro_wpr : 0;
+    return BB_OK;
+}
+
 int bb_solver_traffic(const bb_solver *s, int64_t *unit_bytes, int64_t *pairs_dense) {
     BB_REQUIRE(s != nullptr, "bb_solver_traffic: solver is NULL");
     if (unit_bytes) *unit_bytes = s->n_local * bb::kUnitBytes;

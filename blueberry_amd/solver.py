@@ -312,6 +312,12 @@ class HipEngine(object):
                    "bb_solver_measure_stream_read")
         return float(ms.value)
 
+    def iteration_path(self):
+        """'row_owner' (small one-rank maps: one launch per iteration) or 'units'."""
+        ro, wpr = _lib.c_int(), _lib.c_int()
+        _lib.check(self._lib.bb_solver_iteration_path(self._h, ro, wpr), "bb_solver_iteration_path")
+        return ("row_owner", int(wpr.value)) if ro.value else ("units", 0)
+
     def traffic(self):
         b, p = _lib.c_i64(), _lib.c_i64()
         _lib.check(self._lib.bb_solver_traffic(self._h, b, p), "bb_solver_traffic")

@@ -273,6 +273,10 @@ BB_API int bb_solver_get_step_timing(bb_solver *s, double *step_ms_avg);
  * arithmetic) -- the practical HBM ceiling for the access pattern, to put
  * beside the spec peak in the roofline. */
 BB_API int bb_solver_measure_stream_read(bb_solver *s, int launches, double *ms_avg);
+/* Which kernel bb_solver_iterate runs: row_owner = 1 for the one-launch-per-iteration
+ * path of small one-rank maps (both triangles resident; waves_per_row waves per bin),
+ * 0 for the unit sweep + reduce.  Either pointer may be NULL. */
+BB_API int bb_solver_iteration_path(const bb_solver *s, int *row_owner, int *waves_per_row);
 /* Bytes of wish-distance data the stress+gradient kernel streams per launch on
  * this rank (resident units * unit bytes), and pairs evaluated. */
 BB_API int bb_solver_traffic(const bb_solver *s, int64_t *unit_bytes, int64_t *pairs_dense);
