@@ -52,5 +52,15 @@ BB_ABL_FLAG(kWaveTrace, true);
 #else
 BB_ABL_FLAG(kWaveTrace, false);
 #endif
+#ifdef BB_ABL_NOREFILL_FIRST  // the first unit of a strip does not refill the window (wrong results:
+BB_ABL_FLAG(kNoRefillFirst, true);   // is that unit slow because its refills cannot be issued?)
+#else
+BB_ABL_FLAG(kNoRefillFirst, false);
+#endif
+#ifdef BB_PEEL_FIRST_UNIT      // A/B: round 1's loop shape, the first unit of a strip peeled
+BB_ABL_FLAG(kPeelFirstUnit, true);
+#else
+BB_ABL_FLAG(kPeelFirstUnit, false);
+#endif
 #undef BB_ABL_FLAG
 }  // namespace abl

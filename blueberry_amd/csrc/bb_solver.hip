@@ -1475,6 +1475,15 @@ int bb_solver_measure_stream_read(bb_solver *s, int launches, double *ms_avg) {
 }
 
 #ifdef BB_WAVE_TRACE
+// Diagnostic build only: `times` sweep launches back to back with nothing in between
+// (is a launch's slow first unit a cold instruction cache?).
+BB_API int bb_solver_debug_grad_repeat(bb_solver *s, int times) {
+    BB_TRY(check_ready(s, "bb_solver_debug_grad_repeat"));
+    BB_TRY(bb::enter_device(s->device));
+    for (int k = 0; k < times; ++k) BB_TRY(launch_grad(s));
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    return BB_OK;
+}
 // Diagnostic build only: the stamps of the last stress_grad_kernel launch,
 // 8 x uint64 per wave {start, first unit done, last unit consumed, end, xcc<<32 | hw_id,
 // first load landed, window landed, coordinates landed}.

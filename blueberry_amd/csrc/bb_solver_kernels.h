@@ -459,7 +459,7 @@ __device__ __forceinline__ void pair_step2(f32x2 delta, f32x2 xi, f32x2 yi, f32x
 }
 
 // d[] holds the unit's 8 wave-loads in row order: d[2*r + k] = row r, load k.
-template <bool NT, int OP, bool DEFER>
+template <bool NT, int OP, bool DEFER, bool REFILL = true>
 __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&xrow)[12],
                                                  const float4 *__restrict__ next, StripF32 &st,
                                                  double &stress, __amdgpu_buffer_rsrc_t row_rsrc,
@@ -480,12 +480,12 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&x
         f32x2 rx, ry, rz, qx, qy, qz;  // row-side sums of load 0 / load 1
         pair_step2<0, 0, true, OP>(f32x2{d[2 * r].x, d[2 * r].y}, xi, yi, zi, st, rx, ry, rz, s2);
         pair_step2<0, 1, false, OP>(f32x2{d[2 * r].z, d[2 * r].w}, xi, yi, zi, st, rx, ry, rz, s2);
-        d[2 * r] = stream_load<NT>(next + (2 * r) * 64);
+        if constexpr (REFILL) d[2 * r] = stream_load<NT>(next + (2 * r) * 64);
         // (no sched_barrier here: letting the scheduler mix the rows of a unit measured
         // 1 % faster at N=50k and 6 % faster at 1/8 size; it stays within 125 VGPRs)
         pair_step2<1, 0, true, OP>(f32x2{d[2 * r + 1].x, d[2 * r + 1].y}, xi, yi, zi, st, qx, qy, qz, s2);
         pair_step2<1, 1, false, OP>(f32x2{d[2 * r + 1].z, d[2 * r + 1].w}, xi, yi, zi, st, qx, qy, qz, s2);
-        d[2 * r + 1] = stream_load<NT>(next + (2 * r + 1) * 64);
+        if constexpr (REFILL) d[2 * r + 1] = stream_load<NT>(next + (2 * r + 1) * 64);
         rx += qx; ry += qy; rz += qz;
         float gx = rx.x + rx.y, gy = ry.x + ry.y, gz = rz.x + rz.y;
         if constexpr (!abl::kNoDpp) wave_sum_hi3(gx, gy, gz);
@@ -750,7 +750,8 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
             rowpart + (int64_t)ua * (3 * Lay<T, W>::RPU), 0, (int)((unsigned)(ub - ua) * kRowBytes),
             0x00020000);
 
-        auto unit_step = [&](int u) __attribute__((always_inline)) {
+        // `first`: the peeled first unit of a strip (a timing experiment may treat it apart)
+        auto unit_step = [&](int u, auto first) __attribute__((always_inline)) {
             if constexpr (WPB == 8) {
                 // pace keeping (see the kernel's comment): the partner's count was read
                 // one unit ago, so nothing here waits on LDS
@@ -797,8 +798,8 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
                 float xs12[12];             // scalar registers in the product build
 #pragma unroll
                 for (int q = 0; q < 12; ++q) xs12[q] = xr.get(q);
-                process_unit_f32<NT, OP, DEFER>(d, xs12, unit_ptr<T>(units, un, lane), st, stress,
-                                                row_rsrc, row_voff, stage_slot);
+                process_unit_f32<NT, OP, DEFER, !(decltype(first)::value && abl::kNoRefillFirst)>(
+                    d, xs12, unit_ptr<T>(units, un, lane), st, stress, row_rsrc, row_voff, stage_slot);
             }
             else if constexpr (W && !abl::kF64Generic)
                 process_unit_f64w<NT, OP, DEFER>(d, xr, unit_ptr<T>(units, un, lane), st.xj, st.gc,
@@ -827,12 +828,26 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
                     wave_stamp(stresspart, n_waves_all, w, 7);   // column + row coordinates here
                 }
             }
-            unit_step(u);
-            if (u == ua) wave_stamp(stresspart, n_waves_all, w, 1);   // first unit done
-            ++u;
-            while (u < ub && dc.y == curj) {
-                unit_step(u);
+            if constexpr (abl::kPeelFirstUnit || abl::kWaveTrace) {   // (the trace stamps unit 1)
+                unit_step(u, std::true_type{});
+                if (u == ua) wave_stamp(stresspart, n_waves_all, w, 1);   // first unit done
                 ++u;
+                while (u < ub && dc.y == curj) {
+                    unit_step(u, std::false_type{});
+                    ++u;
+                }
+            } else {
+                // ONE copy of the unit body.  The loop is entered with nothing in flight:
+                // the strip's coordinates have to be here anyway, and they were asked
+                // for after the window -- so the compiler's wait counts inside the loop
+                // are those of the back edge alone, which is what round 1 peeled the first
+                // iteration for.  Same speed as the peeled form at every size
+                // (profiles/r02_peel_ab.txt), a third less code.
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+                do {
+                    unit_step(u, std::false_type{});
+                    ++u;
+                } while (u < ub && dc.y == curj);
             }
             strip_store(slot);
             ++slot;

@@ -31,6 +31,14 @@ for n in sizes:
     e.iterate(5, 1.0 / (2 * n))
     e.sync()
     tm = e.timing()
+    if os.environ.get("BB_TRACE_BACK_TO_BACK"):
+        # the stamps then come from the LAST of several sweeps launched with no other
+        # kernel in between (same code still in the instruction cache?)
+        rep = lib.bb_solver_debug_grad_repeat
+        rep.restype = ctypes.c_int
+        rep.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _lib.check(rep(e._h, int(os.environ["BB_TRACE_BACK_TO_BACK"])))
+        print("(stamps: last of %s back-to-back sweep launches)" % os.environ["BB_TRACE_BACK_TO_BACK"])
     nw = ctypes.c_int64()
     fn(e._h, None, 0, nw)
     buf = numpy.zeros(8 * nw.value, dtype=numpy.uint64)
