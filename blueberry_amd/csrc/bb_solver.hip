@@ -42,7 +42,8 @@ struct bb_solver {
     int2 *d_udesc = nullptr;
     int chunk_q = 0, chunk_r = 0;  // units per wave: n_local = n_waves * q + r
     bool nontemporal = true;
-    int32_t *d_wave_slot = nullptr;
+    int2 *d_wave_slots = nullptr;  // per wave {first private slot, the workgroup's shared slot}
+    int lds_wave_floats = 0;       // LDS region per wave of the sweep, in 4-byte words
     double *d_stresspart = nullptr;
     int64_t *d_blk_ptr = nullptr, *d_blk_chunk = nullptr;    // final stage: one list per block
     int64_t *d_s1_ptr = nullptr, *d_s1_chunk = nullptr;      // stage 1: slices of long lists
@@ -175,7 +176,6 @@ int build_indices(bb_solver *s) {
     s->chunk_q = (int)(s->n_local / nw);
     s->chunk_r = (int)(s->n_local % nw);
     std::vector<int2> wave_range(nw);
-    std::vector<int32_t> wave_slot(nw);
     int64_t chunk_max = 0;
     for (int64_t w = 0; w < nw; ++w) {
         const int64_t a = w * s->chunk_q + std::min<int64_t>(w, s->chunk_r);
@@ -191,23 +191,40 @@ int build_indices(bb_solver *s) {
         const int64_t budget = 156 * 1024 / wgs_per_cu;               // of the CU's 160 KiB
         const int64_t cap = std::min<int64_t>(chunk_max, (budget / s->wpb - 16 - 8) / 48);
         const bool on = !(e && atoi(e) == 0);
-        if ((s->dtype == BB_F32 || s->wide) && on && cap > 0) {
-            s->defer_cap_units = (int)cap;
-            s->defer_lds_bytes = s->wpb * (cap * 48 + 16) + 32;   // + the 8 progress words
-        } else if (s->wpb == 8) {
-            s->defer_lds_bytes = s->wpb * 16 + 32;                // progress words only
-        }
+        if ((s->dtype == BB_F32 || s->wide) && on && cap > 0) s->defer_cap_units = (int)cap;
+        // a wave's LDS region: the parked row sums while it sweeps, its last column partial
+        // (3 * vw elements) at the end; + the 8 progress words of a paired workgroup
+        const int64_t col_words = 3 * vw * bb::elem_size(s->dtype) / 4;
+        s->lds_wave_floats = (int)std::max<int64_t>((int64_t)s->defer_cap_units * 12 + 4, col_words);
+        s->defer_lds_bytes = (int64_t)s->wpb * s->lds_wave_floats * 4 + 32;
     }
-    // column-partial slots: one per (wave, strip) intersection, in wave order
+    // Column-partial slots.  A wave's strips but the last get private slots (it writes them
+    // itself, mid-sweep: rare); the strip a wave ENDS in shares one slot with the other
+    // waves of its workgroup that end in the same strip (summed in LDS by the sweep's
+    // epilogue).  BB_WG_COLSUM=0 gives every wave its own last slot too (for A/B).
     std::vector<int32_t> slot_strip;
-    for (int64_t w = 0; w < nw; ++w) {
-        wave_slot[w] = (int32_t)slot_strip.size();
-        int cur = -1;
-        for (int64_t ul = wave_range[w].x; ul < wave_range[w].y; ++ul) {
-            const int J = s->udesc[ul].y / (int)vw;
-            if (J != cur) {
-                slot_strip.push_back(J);
-                cur = J;
+    std::vector<int2> wave_slots(nw);
+    {
+        const char *e = getenv("BB_WG_COLSUM");
+        const bool share = !(e && atoi(e) == 0);
+        for (int64_t w = 0; w < nw; ++w) {
+            wave_slots[w] = make_int2((int)slot_strip.size(), -1);
+            if (wave_range[w].x >= wave_range[w].y) continue;           // no units
+            int cur = -1;
+            std::vector<int> strips;
+            for (int64_t ul = wave_range[w].x; ul < wave_range[w].y; ++ul) {
+                const int J = s->udesc[ul].y / (int)vw;
+                if (J != cur) { strips.push_back(J); cur = J; }
+            }
+            for (size_t q = 0; q + 1 < strips.size(); ++q) slot_strip.push_back(strips[q]);
+            const int Jlast = strips.back();
+            const bool same_wg = w % s->wpb != 0;
+            if (share && same_wg && wave_slots[w - 1].y >= 0 &&
+                slot_strip[(size_t)wave_slots[w - 1].y] == Jlast) {
+                wave_slots[w].y = wave_slots[w - 1].y;
+            } else {
+                wave_slots[w].y = (int)slot_strip.size();
+                slot_strip.push_back(Jlast);
             }
         }
     }
@@ -271,7 +288,7 @@ int build_indices(bb_solver *s) {
     BB_TRY(dev_alloc((char **)&s->d_V, s->L.n_pad * 3 * es));
     BB_TRY(dev_alloc((char **)&s->d_part, part_total * es));
     BB_TRY(dev_alloc(&s->d_udesc, (int64_t)s->udesc.size()));
-    BB_TRY(dev_alloc(&s->d_wave_slot, nw));
+    BB_TRY(dev_alloc(&s->d_wave_slots, nw));
     BB_TRY(dev_alloc(&s->d_stresspart, nw * 9));   // nw partials (+ 8 stamps per wave, diagnostic build)
     BB_TRY(dev_alloc(&s->d_blk_ptr, nb + 1));
     BB_TRY(dev_alloc(&s->d_blk_chunk, (int64_t)fin_chunk.size()));
@@ -300,7 +317,7 @@ int build_indices(bb_solver *s) {
     hipStream_t st = s->stream;
     BB_HIP_CHECK(hipMemcpyAsync(s->d_udesc, s->udesc.data(), s->udesc.size() * sizeof(int2),
                                 hipMemcpyHostToDevice, st));
-    BB_HIP_CHECK(hipMemcpyAsync(s->d_wave_slot, wave_slot.data(), nw * sizeof(int32_t),
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_wave_slots, wave_slots.data(), nw * sizeof(int2),
                                 hipMemcpyHostToDevice, st));
     BB_HIP_CHECK(hipMemcpyAsync(s->d_blk_ptr, fin_ptr.data(), (nb + 1) * sizeof(int64_t),
                                 hipMemcpyHostToDevice, st));
@@ -351,8 +368,9 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
             s->defer_attr_done |= bit;                                                          \
         }                                                                                       \
         BB_HIP_CHECK(bb::launch(kern, grid, block, (size_t)(LDS), s->stream, units, X,          \
-                                s->d_udesc, s->chunk_q, s->chunk_r, s->d_wave_slot, rowpart,    \
-                                colpart, s->d_stresspart, s->defer_cap_units));                 \
+                                s->d_udesc, s->chunk_q, s->chunk_r, s->d_wave_slots, rowpart,   \
+                                colpart, s->d_stresspart, s->defer_cap_units,                   \
+                                s->lds_wave_floats));                                           \
     } while (0)
 #define BB_LAUNCH2(NTV, OPV, DEF, LDS)                                                          \
     do {                                                                                        \
@@ -365,10 +383,8 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
     do {                                                                                        \
         if ((sizeof(T) == 4 || W) && s->defer_cap_units > 0)                                    \
             BB_LAUNCH2(NTV, OPV, (sizeof(T) == 4 || W), s->defer_lds_bytes);                    \
-        else if ((sizeof(T) == 4 || W) && s->wpb == 8)                                          \
-            BB_LAUNCH2(NTV, OPV, false, s->defer_lds_bytes);                                    \
         else                                                                                    \
-            BB_LAUNCH2(NTV, OPV, false, 0);                                                     \
+            BB_LAUNCH2(NTV, OPV, false, s->defer_lds_bytes);                                    \
     } while (0)
     if (op == kOpMatvec2) {
         if (s->nontemporal) BB_LAUNCH(true, kOpMatvec2); else BB_LAUNCH(false, kOpMatvec2);
@@ -691,7 +707,7 @@ int bb_solver_destroy(bb_solver *s) {
     hipFree(s->d_part);
     if (s->own_exch) hipFree(s->d_exch);
     hipFree(s->d_udesc);
-    hipFree(s->d_wave_slot);
+    hipFree(s->d_wave_slots);
     hipFree(s->d_stresspart);
     hipFree(s->d_blk_ptr);
     hipFree(s->d_blk_chunk);

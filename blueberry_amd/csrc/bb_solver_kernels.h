@@ -621,7 +621,8 @@ __device__ __forceinline__ void wave_stamp(double *stresspart, int n_waves, int 
 //   X          (n_pad, 3) coordinates
 //   udesc      per local unit {i0, j0}
 //   chunk_q/_r units per wave: n_local = n_waves * q + r, the first r waves take q + 1
-//   wave_slot  first column-partial slot of each wave
+//   wave_slots per wave {first private column-partial slot, the workgroup's shared slot of
+//              the strip the wave ENDS in (-1: the wave has no units)}; see the epilogue
 //   rowpart    3*RPU elements per unit, base shifted to the rank's first tile
 //   colpart    3*VW elements per slot
 //   stresspart one double per wave
@@ -650,8 +651,8 @@ __device__ __forceinline__ void wave_stamp(double *stresspart, int n_waves, int 
 template <typename T, bool W, bool NT, int OP, bool DEFER, int WPB>
 __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
     const T *__restrict__ units, const T *__restrict__ X, const int2 *__restrict__ udesc,
-    int chunk_q, int chunk_r, const int32_t *__restrict__ wave_slot, T *__restrict__ rowpart,
-    T *__restrict__ colpart, double *__restrict__ stresspart, int cap_units) {
+    int chunk_q, int chunk_r, const int2 *__restrict__ wave_slots, T *__restrict__ rowpart,
+    T *__restrict__ colpart, double *__restrict__ stresspart, int cap_units, int lds_wave_floats) {
     using Vec = typename Traits<T>::Vec;
     constexpr int VPL = Traits<T>::VPL;
     constexpr int VW = Lay<T, W>::VW;
@@ -668,9 +669,11 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
     double stress = 0.0;
     // DEFER: this wave's parking space, cap_units * 12 floats + 4 dummy words
     extern __shared__ __attribute__((aligned(16))) float row_lds[];
-    const int stage0 = wib * (cap_units * 12 + 4);
-    // WPB = 8: progress words of the 8 waves, behind the parking spaces
-    int *progress = reinterpret_cast<int *>(row_lds + WPB * (cap_units * 12 + 4));
+    // this wave's LDS region: row-sum parking while it sweeps, its last column partial at
+    // the end (lds_wave_floats >= cap_units * 12 + 4 and >= 3 * VW elements of T)
+    const int stage0 = wib * lds_wave_floats;
+    // WPB = 8: progress words of the 8 waves, behind the regions
+    int *progress = reinterpret_cast<int *>(row_lds + WPB * lds_wave_floats);
     int partner_done = 0;
     const int park_from = (ub - ua) > cap_units ? (ub - ua) - cap_units : 0;
     // fp64 2 x 512 units: column selectors of the MFMA row reduction (process_unit_f64w)
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
     for (int v = 0; v < 6; ++v) sel[v] = (lane & 15) == v ? 1.0 : 0.0;
 
     if (ua < ub) {
-        int slot = wave_slot[w];
+        int slot = wave_slots[w].x;
         Vec d[8];  // the unit's 8 wave-loads (8 KiB), in memory order
         // column-strip state: coordinates + gradient accumulators of this lane's columns
         struct Generic { T xj[(Lay<T, W>::LPR)][VPL][3], gc[(Lay<T, W>::LPR)][VPL][3]; };
@@ -849,9 +852,9 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
                     ++u;
                 } while (u < ub && dc.y == curj);
             }
+            if (u >= ub) break;      // the wave's last strip: its column partial goes out below
             strip_store(slot);
             ++slot;
-            if (u >= ub) break;
         }
         if constexpr (WPB == 8) {
             // done: the partner stops yielding
@@ -873,6 +876,47 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
                 const float *src = row_lds + stage0 + 4 * q;
                 dst[q] = make_float4(src[0], src[1], src[2], src[3]);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the region is free again
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the column partial of the wave's LAST strip: into its LDS region (same layout as a
+        // slot in HBM), to be added to its neighbours' below
+        {
+            T *mine = reinterpret_cast<T *>(row_lds + stage0);
+            if constexpr (sizeof(T) == 4)
+                store_strip_f32(st, mine, lane);
+            else
+                store_strip<T, W>(st.gc, mine, lane);
+        }
+    }
+    // One column partial per WORKGROUP and strip, not per wave: consecutive waves sweep
+    // consecutive chunks, almost always of the same strip, so the 4 or 8 partials of a
+    // workgroup are added here, in wave order (fixed), and leave as one slot -- an eighth
+    // of the bytes for the sweep to write and for the reduce to read back.  wave_slots[].y
+    // names the shared slot; waves of one workgroup that end in the same strip carry the
+    // same number (the host deals them, and with BB_WG_COLSUM=0 deals every wave its own).
+    __syncthreads();
+    {
+        constexpr int CH = 3 * VW, NTH = 64 * WPB;
+        const int2 *ws = wave_slots + (int64_t)blockIdx.x * WPB;
+        int k = 0;
+        while (k < WPB) {
+            const int sl = ws[k].y;            // wave-uniform (scalar loads)
+            if (sl < 0) { ++k; continue; }
+            int k2 = k + 1;
+            while (k2 < WPB && ws[k2].y == sl) ++k2;
+            T *dst = colpart + (int64_t)sl * CH;
+#pragma unroll
+            for (int j = 0; j < (CH + NTH - 1) / NTH; ++j) {
+                const int e = (int)threadIdx.x + NTH * j;
+                if (CH % NTH == 0 || e < CH) {
+                    T acc = T(0);
+                    for (int q = k; q < k2; ++q)
+                        acc += reinterpret_cast<const T *>(row_lds + q * lds_wave_floats)[e];
+                    dst[e] = acc;
+                }
+            }
+            k = k2;
         }
     }
 
@@ -886,7 +930,10 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
 // --------------------------------------------------------------------------
 // reduce (+ update) kernel: one workgroup per vw-bin block
 // --------------------------------------------------------------------------
-constexpr int kReduceSlice = 16;  // chunks per stage-1 slice = chunks loaded per round trip
+#ifndef BB_REDUCE_BATCH
+#define BB_REDUCE_BATCH 16
+#endif
+constexpr int kReduceSlice = BB_REDUCE_BATCH;  // chunks per stage-1 slice = chunks loaded per round trip
 
 enum ReduceMode {
     kReduceApply = 0,      // X -= lr * 2 * sum
