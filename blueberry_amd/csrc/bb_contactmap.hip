@@ -28,7 +28,10 @@ struct bb_cm {
 
 namespace {
 
-constexpr int kT = 32;  // tile edge of the normalise kernel
+#ifndef BB_CM_TILE
+#define BB_CM_TILE 32
+#endif
+constexpr int kT = BB_CM_TILE;  // tile edge of the normalise / finalise kernels (kT x 8 threads)
 
 __device__ __forceinline__ double nan_to_num(double v) {
     // numpy.nan_to_num defaults: NaN -> 0, +/-inf -> +/-DBL_MAX
