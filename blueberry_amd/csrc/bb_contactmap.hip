@@ -45,38 +45,58 @@ __device__ __forceinline__ double nan_to_num(double v) {
 // upper tile, writes it back, and writes its mirror through LDS so that every global
 // access is row-contiguous.  A workgroup owns its tile pair alone, and the barrier
 // separates its reads from its mirror writes, so no second matrix is needed.
+// The grid is the triangle itself (nt(nt+1)/2 workgroups, none idle), and a thread has
+// all of its loads in flight before its first store: `m` is read and written through
+// the same pointer, so loads written after a store would wait for it.
 // Traffic per upper pair: 8 B read + 16 B written.
+__device__ __forceinline__ void tile_of(unsigned b, int &TJ, int &TK) {
+    // b = TK (TK + 1) / 2 + TJ with TJ <= TK
+    int t = (int)((__builtin_sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+    while ((unsigned)t * (unsigned)(t + 1) / 2 > b) --t;
+    while ((unsigned)(t + 1) * (unsigned)(t + 2) / 2 <= b) ++t;
+    TK = t;
+    TJ = (int)(b - (unsigned)t * (unsigned)(t + 1) / 2);
+}
+
 __global__ __launch_bounds__(kT * 8) void normalize_kernel(double *m, int64_t d, int64_t n_bins,
                                                            const double *__restrict__ kr,
                                                            const double *__restrict__ krexp) {
     __shared__ double tile[kT][kT + 1];
-    const int TJ = blockIdx.y, TK = blockIdx.x;
-    if (TJ > TK) return;
+    int TJ, TK;
+    tile_of(blockIdx.x, TJ, TK);
     const int tx = threadIdx.x % kT, ty = threadIdx.x / kT;  // 32 x 8
+    constexpr int Q = kT / 8;
+    const int64_t k = (int64_t)TK * kT + tx;
+    double v[Q], den[Q];
 #pragma unroll
-    for (int q = 0; q < kT / 8; ++q) {
+    for (int q = 0; q < Q; ++q) {
+        const int64_t j = (int64_t)TJ * kT + ty + 8 * q;
+        const bool in = j < d && k < d;
+        const bool scaled = j < n_bins && k < n_bins && j <= k;
+        v[q] = in ? m[j * d + k] : 0.0;
+        den[q] = scaled ? kr[j] * kr[k] * krexp[k - j] : 1.0;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
         const int rr = ty + 8 * q;
-        const int64_t j = (int64_t)TJ * kT + rr, k = (int64_t)TK * kT + tx;
-        double v = 0.0;
-        if (j < d && k < d) {
-            v = m[j * d + k];
-            if (j < n_bins && k < n_bins && j <= k) v = v / (kr[j] * kr[k] * krexp[k - j]);
-            if (j <= k || TJ != TK) m[j * d + k] = nan_to_num(v);
-        }
-        tile[rr][tx] = v;
+        const int64_t j = (int64_t)TJ * kT + rr;
+        const bool scaled = j < n_bins && k < n_bins && j <= k;
+        if (scaled) v[q] = v[q] / den[q];
+        if (j < d && k < d && (j <= k || TJ != TK)) m[j * d + k] = nan_to_num(v[q]);
+        tile[rr][tx] = v[q];
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < kT / 8; ++q) {
+    for (int q = 0; q < Q; ++q) {
         const int rr = ty + 8 * q;
         // mirrored element: row k' = TK*kT + rr, column j' = TJ*kT + tx  (k' > j' region)
         const int64_t kk = (int64_t)TK * kT + rr, jj = (int64_t)TJ * kT + tx;
         if (kk < d && jj < d && kk > jj) {
             // row / column n_bins is outside the reference's loop: such a cell keeps its own
             // value (nobody has written it: phase 1 leaves the lower cells alone)
-            const double v = (kk < n_bins && jj < n_bins) ? tile[tx][rr]   // = normalised m[jj][kk]
+            const double w = (kk < n_bins && jj < n_bins) ? tile[tx][rr]   // = normalised m[jj][kk]
                                                           : m[kk * d + jj];
-            m[kk * d + jj] = nan_to_num(v);
+            m[kk * d + jj] = nan_to_num(w);
         }
     }
 }
@@ -115,7 +135,10 @@ __global__ void scatter_store_kernel(const double *__restrict__ tr, int64_t n, d
 // Column marginals: one thread per column, rows added IN ORDER (that is numpy's
 // sum(axis=0) for a C-contiguous matrix, bit for bit); kUnroll loads are in flight
 // before the dependent adds so that the sweep runs near HBM speed all the same.
-constexpr int kSumUnroll = 16;
+#ifndef BB_CM_SUM_UNROLL
+#define BB_CM_SUM_UNROLL 16
+#endif
+constexpr int kSumUnroll = BB_CM_SUM_UNROLL;
 __global__ __launch_bounds__(128) void column_sums_kernel(const double *__restrict__ m, int64_t d,
                                                           double *__restrict__ sums) {
     const int64_t c = (int64_t)blockIdx.x * 128 + threadIdx.x;
@@ -593,8 +616,10 @@ int bb_cm_normalize(bb_cm *cm, int64_t n_bins, const double *KRnorm, const doubl
             e = hipMemcpyAsync(ke.p, KRexpected, (size_t)n_bins * sizeof(double), hipMemcpyHostToDevice, st);
     }
     if (e == hipSuccess) {
-        const unsigned nt = (unsigned)((d + kT - 1) / kT);
-        e = bb::launch(normalize_kernel, dim3(nt, nt), dim3(kT * 8), 0, st, cm->m, d, n_bins,
+        const uint64_t nt = (uint64_t)((d + kT - 1) / kT);
+        if (nt * (nt + 1) / 2 > 0x7fffffffull)
+            return bb::fail(BB_ERR_INVALID, "bb_cm_normalize: matrix too large for one launch");
+        e = bb::launch(normalize_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(kT * 8), 0, st, cm->m, d, n_bins,
                        (const double *)kr.p, (const double *)ke.p);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);

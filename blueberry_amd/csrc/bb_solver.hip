@@ -598,7 +598,7 @@ struct PeerHandle {
 static_assert(sizeof(PeerHandle) <= BB_PEER_HANDLE_BYTES, "handle blob too small");
 static_assert(offsetof(PeerTable<float>, flag) == kMaxPeers * sizeof(void *) &&
                   offsetof(PeerTable<double>, flag) == kMaxPeers * sizeof(void *),
-              "peer_wait_kernel takes the flag pointers as the second half of a PeerTable");
+              "peer_receive_kernel takes the flag pointers as the second half of a PeerTable");
 constexpr uint64_t kPeerMagic = 0x6262706565723031ull;  // "bbpeer01"
 
 int64_t peer_flags_offset(const bb_solver *s) {
@@ -1255,20 +1255,18 @@ int bb_solver_iterate_peer(bb_solver *s, int64_t iters, double lr) {
         // the flag pointers are the second half of a PeerTable (same for both parities)
         unsigned long long *const *poison =
             (unsigned long long *const *)((const char *)s->d_peer_table + kMaxPeers * sizeof(void *));
-        BB_HIP_CHECK(bb::launch(peer_wait_kernel, dim3(1), dim3(64), 0, s->stream, flags, s->world,
-                                s->peer_seq, s->d_peer_state, poison, s->peer_limit_ticks));
         if (s->dtype == BB_F32)
-            BB_HIP_CHECK(bb::launch(peer_apply_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
-                                    (float *)s->d_X, (float *)s->d_V, (const float *)arena,
-                                    s->world, s->peer_slot_elems, n3, (float)lr,
+            BB_HIP_CHECK(bb::launch(peer_receive_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
+                                    (float *)s->d_X, (float *)s->d_V, (const float *)arena, flags,
+                                    poison, s->world, s->peer_slot_elems, n3, (float)lr,
                                     (float)s->momentum, s->d_stress_hist + s->hist_n, s->peer_seq,
-                                    (const PeerState *)s->d_peer_state));
+                                    s->d_peer_state, s->peer_limit_ticks));
         else
-            BB_HIP_CHECK(bb::launch(peer_apply_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
-                                    (double *)s->d_X, (double *)s->d_V, (const double *)arena,
-                                    s->world, s->peer_slot_elems, n3, lr, s->momentum,
-                                    s->d_stress_hist + s->hist_n, s->peer_seq,
-                                    (const PeerState *)s->d_peer_state));
+            BB_HIP_CHECK(bb::launch(peer_receive_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
+                                    (double *)s->d_X, (double *)s->d_V, (const double *)arena, flags,
+                                    poison, s->world, s->peer_slot_elems, n3, lr, s->momentum,
+                                    s->d_stress_hist + s->hist_n, s->peer_seq, s->d_peer_state,
+                                    s->peer_limit_ticks));
         s->hist_n++;
     }
     return BB_OK;

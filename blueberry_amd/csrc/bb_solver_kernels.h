@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(kRedWG) void reduce_kernel(ReduceParams<T> p) {
     const int e = (int)blockIdx.y * kRedWG + tid;      // element of the block, < CH
     __shared__ __attribute__((aligned(16))) T push_stage[kRedWG];   // peer mode only
     // peer mode: once this rank's exchange has failed it stops delivering (the status
-    // word is only ever written by peer_wait_kernel, i.e. between launches: uniform)
+    // word is only ever written by peer_receive_kernel, i.e. between reduce launches: uniform)
     const bool peer_live =
         p.mode != kReducePeer ||
         __hip_atomic_load(&p.peer_state->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
@@ -1099,57 +1099,73 @@ __global__ __launch_bounds__(kRedWG) void reduce_kernel(ReduceParams<T> p) {
 }
 
 
-// Peer exchange, receiving side, part 1: ONE wave waits until every source rank's flag
-// has reached `seq` and publishes the outcome for the whole update launch that follows
-// (state->verdict = seq).  The wait is bounded: past `limit` ticks of the constant-rate
-// clock -- or when a peer has left its poison flag -- the sticky status word is set,
-// the verdict is withheld, and this rank's own flag on every peer is poisoned so that
-// nobody goes on consuming partials computed from coordinates that no longer move.
-// Deciding in one place is what keeps X whole: with every workgroup of the update
-// polling for itself, some could time out while later ones saw the flags arrive.
-__global__ __launch_bounds__(64) void peer_wait_kernel(const unsigned long long *flags, int world,
-                                                       unsigned long long seq, PeerState *state,
-                                                       unsigned long long *const *poison_flags,
-                                                       long long limit) {
-    const int lane = threadIdx.x;
-    bool all_ok = false;
-    if (__hip_atomic_load(&state->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        // The whole wave polls together until EVERY flag is there: a lane whose flag
-        // has arrived keeps reading it, so a poison that lands later is still seen.
-        const long long t0 = wall_clock64();
-        for (;;) {
-            const unsigned long long f =
-                lane < world ? __hip_atomic_load(flags + 8 * lane, __ATOMIC_ACQUIRE,
-                                                 __HIP_MEMORY_SCOPE_SYSTEM)
-                             : seq;
-            if (__ballot(f == kPeerPoison) != 0) break;
-            if (__ballot(f >= seq) == __ballot(1)) { all_ok = true; break; }
-            if (__ballot(wall_clock64() - t0 > limit) != 0) break;   // wave-uniform exits only
-            __builtin_amdgcn_s_sleep(4);
-        }
-    }
-    if (all_ok) {
-        if (lane == 0)
-            __hip_atomic_store(&state->verdict, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        if (lane == 0) atomicExch(&state->status, 1);
-        if (lane < world)
-            __hip_atomic_store(poison_flags[lane], kPeerPoison, __ATOMIC_RELEASE,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-// Part 2: X <- X + (mu V - lr * sum over ranks, in rank order), only if the wait
-// before it published this launch's sequence number (every workgroup reads the same
-// word, so the step is applied whole or not at all).  `arena` is this parity's first
-// slot; it is uncached memory, read past L1/L2.
+// Peer exchange, receiving side -- one launch.  Wave 0 of workgroup 0 waits until every
+// source rank's flag has reached `seq` and publishes the outcome (state->verdict = seq);
+// wave 0 of every other workgroup polls that LOCAL word and the sticky status, so the
+// step is applied by all workgroups or by none.  The wait is bounded: past `limit`
+// ticks of the constant-rate clock -- or when a peer has left its poison flag -- the
+// status word is set, the verdict is withheld, and this rank's own flag on every peer
+// is poisoned so that nobody goes on consuming partials computed from coordinates that
+// no longer move.  Deciding in one place is what keeps X whole: with every workgroup
+// polling the remote flags for itself, some could time out while later ones saw them
+// arrive.  Workgroup 0 is dispatched first, so the deciding wave is resident before any
+// wave that waits for it; it waits for other devices only.
+// Then X <- X + (mu V - lr * sum over ranks, in rank order).  `arena` is this parity's
+// first slot; it is uncached memory, read past L1/L2.
 template <typename T>
-__global__ __launch_bounds__(256) void peer_apply_kernel(
-    T *__restrict__ X, T *__restrict__ V, const T *arena, int world, int64_t slot_elems,
-    int64_t n3, T lr, T mu, double *stress_out, unsigned long long seq, const PeerState *state) {
-    if (__hip_atomic_load(&state->verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != seq)
-        return;
+__global__ __launch_bounds__(256) void peer_receive_kernel(
+    T *__restrict__ X, T *__restrict__ V, const T *arena, const unsigned long long *flags,
+    unsigned long long *const *poison_flags, int world, int64_t slot_elems, int64_t n3, T lr, T mu,
+    double *stress_out, unsigned long long seq, PeerState *state, long long limit) {
     const int tid = threadIdx.x;
+    __shared__ int go;
+    if (tid < 64) {
+        bool all_ok = false;
+        if (blockIdx.x == 0) {
+            const int lane = tid;
+            if (__hip_atomic_load(&state->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                // The whole wave polls together until EVERY flag is there: a lane whose
+                // flag has arrived keeps reading it, so a poison that lands later is seen.
+                const long long t0 = wall_clock64();
+                for (;;) {
+                    const unsigned long long f =
+                        lane < world ? __hip_atomic_load(flags + 8 * lane, __ATOMIC_ACQUIRE,
+                                                         __HIP_MEMORY_SCOPE_SYSTEM)
+                                     : seq;
+                    if (__ballot(f == kPeerPoison) != 0) break;
+                    if (__ballot(f >= seq) == __ballot(1)) { all_ok = true; break; }
+                    if (__ballot(wall_clock64() - t0 > limit) != 0) break;   // wave-uniform exits only
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            if (all_ok) {
+                if (lane == 0)
+                    __hip_atomic_store(&state->verdict, seq, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (lane < world)
+                    __hip_atomic_store(poison_flags[lane], kPeerPoison, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                if (lane == 0)
+                    __hip_atomic_store(&state->status, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            // ends when workgroup 0 has decided, one way or the other (it always does:
+            // its own wait is bounded)
+            for (;;) {
+                if (__hip_atomic_load(&state->verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) ==
+                    seq) { all_ok = true; break; }
+                if (__hip_atomic_load(&state->status, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                    break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (tid == 0) go = all_ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!go) return;
+    // The arena is read with system-scope loads, which go past L1/L2 to memory: issued
+    // after the barrier they cannot be older than the flags wave 0 acquired.
     const int64_t e = (int64_t)blockIdx.x * 256 + tid;
     if (e < n3) {
         // all slots are requested before the first add (one memory round trip per
