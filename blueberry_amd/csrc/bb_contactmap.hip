@@ -136,12 +136,16 @@ __global__ void scatter_store_kernel(const double *__restrict__ tr, int64_t n, d
 // sum(axis=0) for a C-contiguous matrix, bit for bit); kUnroll loads are in flight
 // before the dependent adds so that the sweep runs near HBM speed all the same.
 #ifndef BB_CM_SUM_UNROLL
-#define BB_CM_SUM_UNROLL 16
+#define BB_CM_SUM_UNROLL 64
 #endif
 constexpr int kSumUnroll = BB_CM_SUM_UNROLL;
-__global__ __launch_bounds__(128) void column_sums_kernel(const double *__restrict__ m, int64_t d,
+#ifndef BB_CM_SUM_WG
+#define BB_CM_SUM_WG 128
+#endif
+constexpr int kSumWG = BB_CM_SUM_WG;
+__global__ __launch_bounds__(kSumWG) void column_sums_kernel(const double *__restrict__ m, int64_t d,
                                                           double *__restrict__ sums) {
-    const int64_t c = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    const int64_t c = (int64_t)blockIdx.x * kSumWG + threadIdx.x;
     if (c >= d) return;
     const double *p = m + c;
     double acc = 0.0;
@@ -635,7 +639,7 @@ int bb_cm_marginals(bb_cm *cm, double *sums) {
     hipError_t e = s.alloc((size_t)cm->d * 8);
     if (e != hipSuccess)
         return bb::fail(BB_ERR_NOMEM, std::string("bb_cm_marginals: ") + hipGetErrorString(e));
-    e = bb::launch(column_sums_kernel, dim3((unsigned)((cm->d + 127) / 128)), dim3(128), 0,
+    e = bb::launch(column_sums_kernel, dim3((unsigned)((cm->d + kSumWG - 1) / kSumWG)), dim3(kSumWG), 0,
                    cm->stream, (const double *)cm->m, cm->d, (double *)s.p);
     if (e == hipSuccess) e = hipStreamSynchronize(cm->stream);
     if (e == hipSuccess) e = hipMemcpy(sums, s.p, (size_t)cm->d * 8, hipMemcpyDeviceToHost);
@@ -655,7 +659,7 @@ int bb_cm_filter(bb_cm *cm, double threshold, int64_t *d_new, uint8_t *keep_out)
     if (e != hipSuccess)
         return bb::fail(BB_ERR_NOMEM, std::string("bb_cm_filter: ") + hipGetErrorString(e));
     hipStream_t st = cm->stream;
-    e = bb::launch(column_sums_kernel, dim3((unsigned)((d + 127) / 128)), dim3(128), 0, st,
+    e = bb::launch(column_sums_kernel, dim3((unsigned)((d + kSumWG - 1) / kSumWG)), dim3(kSumWG), 0, st,
                    (const double *)cm->m, d, (double *)sums.p);
     if (e == hipSuccess)
         e = bb::launch(keep_scan_kernel, dim3(1), dim3(1024), 0, st, (const double *)sums.p, d,

@@ -1152,13 +1152,18 @@ __global__ __launch_bounds__(256) void peer_receive_kernel(
         } else {
             // ends when workgroup 0 has decided, one way or the other (it always does:
             // its own wait is bounded)
+            // (relaxed polls and ONE acquire fence at the end: an acquire is a cache
+            // invalidate on this part, and 200 waves issuing one per poll cost 12 us)
             for (;;) {
-                if (__hip_atomic_load(&state->verdict, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) ==
-                    seq) { all_ok = true; break; }
-                if (__hip_atomic_load(&state->status, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0)
-                    break;
+                const unsigned long long vd =
+                    __hip_atomic_load(&state->verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int st =
+                    __hip_atomic_load(&state->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (vd == seq) { all_ok = true; break; }
+                if (st != 0) break;
                 __builtin_amdgcn_s_sleep(2);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         if (tid == 0) go = all_ok ? 1 : 0;
     }
