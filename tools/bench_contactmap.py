@@ -31,7 +31,14 @@ for n_bins in [int(a) for a in sys.argv[1:]] or [24926]:
     kr = 0.5 + rng.random(n_bins); ke = 50.0 / (1.0 + numpy.arange(n_bins)) + 0.1
     print("== n_bins %d (matrix %.2f GB fp64), %d triples" % (n_bins, d * d * 8 / 1e9, nnz))
     t, cm = timed(lambda: bb.ContactMap.from_triples(triples, res, n_bins, KRnorm=kr, KRexpected=ke), 2)
-    print("scatter (H2D of the triples + zero fill + 2 passes)  %.1f ms  -> %.1f GB/s of %.2f GB"
+    print("ContactMap.from_triples, whole call (host prep + create + scatter + regions)  %.1f ms" % (t * 1e3))
+    from blueberry_amd import _lib
+    from blueberry_amd.datatypes import _DeviceMatrix
+    cols = numpy.ascontiguousarray(triples.T)
+    dm = _DeviceMatrix(d, 0)
+    t, _ = timed(lambda: _lib.check(dm._lib.bb_cm_scatter(dm._h, _lib.as_f64_ptr(cols), nnz, res), "bb_cm_scatter"))
+    dm.close()
+    print("scatter: the bb_cm_scatter call (H2D of the triples + zero fill + 2 passes)  %.1f ms  -> %.1f GB/s of %.2f GB"
           % (t * 1e3, (nnz * 40 + d * d * 8) / t / 1e9, (nnz * 40 + d * d * 8) / 1e9))
     def norm():
         cm._KRnorm, cm._KRexpected = kr, ke
