@@ -161,6 +161,8 @@ __global__ __launch_bounds__(kSumWG) void column_sums_kernel(const double *__res
     sums[c] = acc;
 }
 
+constexpr int64_t kFilterBounceElems = 8 << 20;   // 64 MiB of doubles between gather and copy-back
+
 // keep[c] = sums[c] > threshold (NaN: false, as numpy), and the exclusive prefix sum of
 // keep -> old_of_new[]; one workgroup, sequential over chunks of 1024 columns.
 __global__ __launch_bounds__(1024) void keep_scan_kernel(const double *__restrict__ sums, int64_t d,
@@ -193,15 +195,16 @@ __global__ __launch_bounds__(1024) void keep_scan_kernel(const double *__restric
     if (tid == 0) *n_kept = base;
 }
 
-// out (dn, dn) = in[kept rows][:, kept columns]
+// tmp (r1 - r0, dn) = in[kept rows r0..r1)[:, kept columns]
 __global__ __launch_bounds__(256) void gather_kernel(const double *__restrict__ in, int64_t d,
                                                      const int *__restrict__ old_of_new,
-                                                     double *__restrict__ out, int64_t dn) {
+                                                     double *__restrict__ tmp, int64_t dn,
+                                                     int64_t r0, int64_t r1) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= dn) return;
     const int64_t oc = old_of_new[c];
-    for (int64_t r = blockIdx.y; r < dn; r += gridDim.y)
-        out[r * dn + c] = in[(int64_t)old_of_new[r] * d + oc];
+    for (int64_t r = r0 + blockIdx.y; r < r1; r += gridDim.y)
+        tmp[(r - r0) * dn + c] = in[(int64_t)old_of_new[r] * d + oc];
 }
 
 // ---- eigenvector (datatypes.pyx:216-235): Lanczos on the resident matrix -----------
@@ -670,22 +673,32 @@ int bb_cm_filter(bb_cm *cm, double threshold, int64_t *d_new, uint8_t *keep_out)
     if (e == hipSuccess && keep_out) e = hipMemcpy(keep_out, keep.p, (size_t)d, hipMemcpyDeviceToHost);
     if (e != hipSuccess)
         return bb::fail(BB_ERR_HIP, std::string("bb_cm_filter: ") + hipGetErrorString(e));
-    double *out = nullptr;
-    e = hipMalloc((void **)&out, (size_t)std::max<int64_t>(dn * dn, 1) * sizeof(double));
-    if (e != hipSuccess)
-        return bb::fail(BB_ERR_NOMEM, std::string("bb_cm_filter: ") + hipGetErrorString(e));
-    if (dn > 0) {
-        e = bb::launch(gather_kernel,
-                       dim3((unsigned)((dn + 255) / 256), (unsigned)std::min<int64_t>(dn, 32768)), dim3(256), 0,
-                       st, (const double *)cm->m, d, (const int *)idx.p, out, dn);
+    // Compaction IN PLACE, a band of rows at a time through a small bounce buffer: the
+    // new matrix is the old one read in order with elements left out, so new row r lands at
+    // [r dn, (r+1) dn), in front of every element a later row still needs (those start at
+    // old_row(r+1) d >= (r+1) dn).  No matrix-sized allocation: a fresh hipMalloc of 1-5 GB
+    // costs 170-350 ms on this platform (tools/alloc_probe.py), the whole filter 3 ms.
+    // The buffer keeps its size; only d shrinks.
+    if (dn > 0 && dn < d) {
+        const int64_t band = std::max<int64_t>(1, std::min<int64_t>(dn, kFilterBounceElems / dn));
+        bb::DevBuf tmp;
+        e = tmp.alloc((size_t)(band * dn) * sizeof(double));
+        if (e != hipSuccess)
+            return bb::fail(BB_ERR_NOMEM, std::string("bb_cm_filter: ") + hipGetErrorString(e));
+        for (int64_t r0 = 0; r0 < dn && e == hipSuccess; r0 += band) {
+            const int64_t r1 = std::min(dn, r0 + band);
+            e = bb::launch(gather_kernel,
+                           dim3((unsigned)((dn + 255) / 256), (unsigned)std::min<int64_t>(r1 - r0, 32768)),
+                           dim3(256), 0, st, (const double *)cm->m, d, (const int *)idx.p,
+                           (double *)tmp.p, dn, r0, r1);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(cm->m + r0 * dn, tmp.p, (size_t)((r1 - r0) * dn) * sizeof(double),
+                                   hipMemcpyDeviceToDevice, st);
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess)
+            return bb::fail(BB_ERR_HIP, std::string("bb_cm_filter: ") + hipGetErrorString(e));
     }
-    if (e != hipSuccess) {
-        (void)hipFree(out);
-        return bb::fail(BB_ERR_HIP, std::string("bb_cm_filter: ") + hipGetErrorString(e));
-    }
-    (void)hipFree(cm->m);
-    cm->m = out;
     cm->d = dn;
     if (d_new) *d_new = dn;
     return BB_OK;
