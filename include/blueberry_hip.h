@@ -296,7 +296,7 @@ BB_API int bb_cm_create(bb_cm **out, int64_t d, int device);   /* zero-filled (p
 BB_API int bb_cm_destroy(bb_cm *cm);
 BB_API int bb_cm_dim(const bb_cm *cm, int64_t *d);
 /* The resident matrix itself (row-major, leading dimension d) for callers that share
- * the HIP context; borrowed, valid until the next bb_cm_filter / bb_cm_destroy. */
+ * the HIP context; borrowed, valid until bb_cm_destroy (bb_cm_filter changes d). */
 BB_API int bb_cm_device_ptr(const bb_cm *cm, const double **dev_matrix, int64_t *d, int *device);
 BB_API int bb_cm_upload(bb_cm *cm, const double *matrix, int64_t ld);   /* host (d,d) -> device */
 BB_API int bb_cm_download(bb_cm *cm, double *matrix, int64_t ld);       /* device -> host (d,d) */
@@ -313,8 +313,9 @@ BB_API int bb_cm_normalize(bb_cm *cm, int64_t n_bins, const double *KRnorm,
 BB_API int bb_cm_marginals(bb_cm *cm, double *sums);
 /* ContactMap.filter (pyx:140-141): keep the rows and columns whose marginal is
  * > threshold (a NaN marginal is dropped, as `NaN > t` is false in numpy).  The
- * resident matrix becomes (d_new, d_new); keep_out (d bytes, may be NULL) receives the
- * 0/1 mask over the OLD indices. */
+ * resident matrix becomes (d_new, d_new), compacted in place (same device pointer, leading
+ * dimension d_new; the allocation keeps its size); keep_out (d bytes, may be NULL)
+ * receives the 0/1 mask over the OLD indices. */
 BB_API int bb_cm_filter(bb_cm *cm, double threshold, int64_t *d_new, uint8_t *keep_out);
 /* y = M x over the resident matrix (x, y: d doubles on the host): one HBM sweep. */
 BB_API int bb_cm_symv(bb_cm *cm, const double *x, double *y);
