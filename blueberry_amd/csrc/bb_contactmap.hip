@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "bb_common.h"
+#include <cstdlib>
 
 struct bb_cm {
     int device = 0;
@@ -680,7 +681,11 @@ int bb_cm_filter(bb_cm *cm, double threshold, int64_t *d_new, uint8_t *keep_out)
     // costs 170-350 ms on this platform (tools/alloc_probe.py), the whole filter 3 ms.
     // The buffer keeps its size; only d shrinks.
     if (dn > 0 && dn < d) {
-        const int64_t band = std::max<int64_t>(1, std::min<int64_t>(dn, kFilterBounceElems / dn));
+        // BB_CM_FILTER_BOUNCE (elements): tests shrink the bounce buffer so that small
+        // matrices go through many bands and a ragged last one
+        int64_t bounce = kFilterBounceElems;
+        if (const char *v = getenv("BB_CM_FILTER_BOUNCE")) bounce = std::max<int64_t>(1, atoll(v));
+        const int64_t band = std::max<int64_t>(1, std::min<int64_t>(dn, bounce / dn));
         bb::DevBuf tmp;
         e = tmp.alloc((size_t)(band * dn) * sizeof(double));
         if (e != hipSuccess)

@@ -168,6 +168,29 @@ def test_contactmap_filter_vs_numpy_ragged(d):
         assert cm.n_bins == want.shape[0]
 
 
+@pytest.mark.parametrize("bounce", [1, 7, 1000, 20000])
+def test_contactmap_filter_in_place_bands(bounce, monkeypatch):
+    """The filter compacts the resident matrix in place, a band of rows at a time through
+    a bounce buffer; with the buffer shrunk to `bounce` elements a 300-bin matrix goes
+    through 1-row bands (bounce < row), many bands with a ragged last one, and one band.
+    Cases: scattered drops, only the first rows dropped (every new row moves far), only
+    the last dropped (rows stay, columns shrink), all but one dropped."""
+    monkeypatch.setenv("BB_CM_FILTER_BOUNCE", str(bounce))
+    d = 300
+    rng = numpy.random.default_rng(bounce)
+    base = rng.random((d, d))
+    base = base + base.T
+    masks = [rng.random(d) < 0.6, numpy.arange(d) >= 120, numpy.arange(d) < 170,
+             numpy.arange(d) == 211]
+    for keep in masks:
+        m = base * numpy.outer(keep, keep)          # dropped bins have zero marginals
+        cm = bb.ContactMap.from_matrix(m)
+        cm.filter(0.0)
+        want = m[keep][:, keep]
+        assert cm.shape == want.shape
+        assert numpy.array_equal(cm.to_host(), want)
+
+
 def test_contactmap_resident_pipeline_feeds_the_solver(oracle):
     """triples -> ContactMap (scatter on the device) -> normalize -> filter -> fit, the
     matrix never leaving HBM: equals the oracle's chain on the host (scatter, normalise,
