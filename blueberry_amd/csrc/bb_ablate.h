@@ -62,5 +62,10 @@ BB_ABL_FLAG(kPeelFirstUnit, true);
 #else
 BB_ABL_FLAG(kPeelFirstUnit, false);
 #endif
+#ifdef BB_WARMUP               // experiment: n x 4 dummy packed FMAs per wave while its first loads
+constexpr int kWarmup = BB_WARMUP;   // are in flight (does the first unit run slow because the VALUs start cold?)
+#else
+constexpr int kWarmup = 0;
+#endif
 #undef BB_ABL_FLAG
 }  // namespace abl

@@ -825,6 +825,19 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
         for (;;) {
             const int curj = dc.y;
             strip_load(curj);
+            if constexpr (abl::kWarmup > 0) {
+                if (u == ua) {
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    f2 a0 = {1.f, 1.f}, a1 = a0, a2 = a0, a3 = a0;
+                    const f2 m = {0.999f, 1.001f};
+                    for (int i = 0; i < abl::kWarmup; ++i)
+                        asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n\tv_pk_fma_f32 %1, %1, %4, %4\n\t"
+                                     "v_pk_fma_f32 %2, %2, %4, %4\n\tv_pk_fma_f32 %3, %3, %4, %4"
+                                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
+                                     : "v"(m));
+                    asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3));
+                }
+            }
             if constexpr (abl::kWaveTrace) {
                 if (u == ua) {
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
