@@ -91,6 +91,8 @@ SIGNATURES = {
     "bb_cm_upload": (c_int, [c_void_p, p_dbl, c_i64]),
     "bb_cm_download": (c_int, [c_void_p, p_dbl, c_i64]),
     "bb_cm_scatter": (c_int, [c_void_p, p_dbl, c_i64, c_i32]),
+    "bb_cm_scatter_ex": (c_int, [c_void_p, p_dbl, c_i64, c_i32, c_i32, ctypes.POINTER(ctypes.c_uint8),
+                                 ctypes.POINTER(c_i32)]),
     "bb_cm_normalize": (c_int, [c_void_p, c_i64, p_dbl, p_dbl]),
     "bb_cm_marginals": (c_int, [c_void_p, p_dbl]),
     "bb_cm_filter": (c_int, [c_void_p, c_dbl, p_i64, ctypes.POINTER(ctypes.c_uint8)]),

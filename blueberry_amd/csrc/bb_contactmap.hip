@@ -105,14 +105,25 @@ __global__ __launch_bounds__(kT * 8) void normalize_kernel(double *m, int64_t d,
 // Scatter, pass 1: every cell a triple names records the LAST triple that names it
 // (integer atomicMax of t + 1 on the cell's own 8 bytes: the matrix was zeroed first,
 // and a count is only stored in pass 2).  No winner array the size of the matrix.
-__global__ void scatter_mark_kernel(const double *__restrict__ tr, int64_t n, double resolution,
-                                    int64_t d, double *m, int *__restrict__ bad) {
+// Element c of triple t is tr[t * st + c * sc]: (1, n) for the reference's column-major
+// array (pyx:111-113), (3, 1) for C-ordered (n, 3) rows.  `present` (d bytes, may be NULL)
+// gets a 1 for every bin a position falls in, `offgrid` a 1 if some position is not exactly
+// bin * resolution -- what the caller needs to write down `regions` without sorting.
+__global__ void scatter_mark_kernel(const double *__restrict__ tr, int64_t n, int64_t st, int64_t sc,
+                                    double resolution, int64_t d, double *m, int *__restrict__ bad,
+                                    unsigned char *__restrict__ present, int *__restrict__ offgrid) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    const int j = (int)(tr[t] / resolution), k = (int)(tr[n + t] / resolution);
+    const double pj = tr[t * st], pk = tr[t * st + sc];
+    const int j = (int)(pj / resolution), k = (int)(pk / resolution);
     if (j < 0 || k < 0 || j >= d || k >= d) {
         atomicExch(bad, 1);
         return;
+    }
+    if (present != nullptr) {
+        present[j] = 1;
+        present[k] = 1;
+        if ((double)j * resolution != pj || (double)k * resolution != pk) *offgrid = 1;
     }
     unsigned long long *cells = reinterpret_cast<unsigned long long *>(m);
     atomicMax(&cells[(int64_t)j * d + k], (unsigned long long)(t + 1));
@@ -120,13 +131,13 @@ __global__ void scatter_mark_kernel(const double *__restrict__ tr, int64_t n, do
 }
 
 // Pass 2: the winning triple stores its count (plain stores, as pyx:115-116).
-__global__ void scatter_store_kernel(const double *__restrict__ tr, int64_t n, double resolution,
-                                     int64_t d, double *m) {
+__global__ void scatter_store_kernel(const double *__restrict__ tr, int64_t n, int64_t st, int64_t sc,
+                                     double resolution, int64_t d, double *m) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    const int j = (int)(tr[t] / resolution), k = (int)(tr[n + t] / resolution);
+    const int j = (int)(tr[t * st] / resolution), k = (int)(tr[t * st + sc] / resolution);
     if (j < 0 || k < 0 || j >= d || k >= d) return;
-    const double c = tr[2 * n + t];
+    const double c = tr[t * st + 2 * sc];
     unsigned long long *cells = reinterpret_cast<unsigned long long *>(m);
     // a cell still holding t + 1 is ours; j == k names one cell twice, harmlessly
     if (cells[(int64_t)j * d + k] == (unsigned long long)(t + 1)) m[(int64_t)j * d + k] = c;
@@ -569,41 +580,55 @@ int bb_cm_download(bb_cm *cm, double *matrix, int64_t ld) {
     return BB_OK;
 }
 
-int bb_cm_scatter(bb_cm *cm, const double *triples, int64_t n, int32_t resolution) {
+int bb_cm_scatter_ex(bb_cm *cm, const double *triples, int64_t n, int32_t resolution,
+                     int32_t row_major, uint8_t *present, int32_t *on_grid) {
     BB_TRY(cm_check(cm, "bb_cm_scatter"));
     BB_REQUIRE(n >= 0 && (triples != nullptr || n == 0), "bb_cm_scatter: bad triples");
     BB_REQUIRE(n < (int64_t)0x7fffffff, "bb_cm_scatter: too many triples");
     BB_REQUIRE(resolution != 0, "bb_cm_scatter: resolution is 0");
+    BB_REQUIRE((present == nullptr) == (on_grid == nullptr),
+               "bb_cm_scatter_ex: present and on_grid go together");
     const int64_t d = cm->d;
-    bb::DevBuf tr, bad;
+    const bool want = present != nullptr;
+    bb::DevBuf tr, bad, pres;
     hipError_t e = tr.alloc((size_t)n * 3 * sizeof(double));
-    if (e == hipSuccess) e = bad.alloc(sizeof(int));
+    if (e == hipSuccess) e = bad.alloc(2 * sizeof(int));          // {bad, off the grid}
+    if (e == hipSuccess && want) e = pres.alloc((size_t)d);
     if (e != hipSuccess)
         return bb::fail(BB_ERR_NOMEM, std::string("bb_cm_scatter: ") + hipGetErrorString(e));
     hipStream_t st = cm->stream;
-    int host_bad = 0;
+    int host_flags[2] = {0, 0};
     if (n > 0) e = hipMemcpyAsync(tr.p, triples, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemsetAsync(cm->m, 0, (size_t)d * d * sizeof(double), st);  // pyx:99
-    if (e == hipSuccess) e = hipMemsetAsync(bad.p, 0, sizeof(int), st);
+    if (e == hipSuccess) e = hipMemsetAsync(bad.p, 0, 2 * sizeof(int), st);
+    if (e == hipSuccess && want) e = hipMemsetAsync(pres.p, 0, (size_t)d, st);
     if (e == hipSuccess && n > 0) {
         const unsigned grid = (unsigned)((n + 255) / 256);
-        e = bb::launch(scatter_mark_kernel, dim3(grid), dim3(256), 0, st, (const double *)tr.p, n,
-                       (double)resolution, d, cm->m, (int *)bad.p);
+        const int64_t ts = row_major ? 3 : 1, cs = row_major ? 1 : n;
+        e = bb::launch(scatter_mark_kernel, dim3(grid), dim3(256), 0, st, (const double *)tr.p, n, ts,
+                       cs, (double)resolution, d, cm->m, (int *)bad.p,
+                       (unsigned char *)(want ? pres.p : nullptr), (int *)bad.p + 1);
         if (e == hipSuccess)
             e = bb::launch(scatter_store_kernel, dim3(grid), dim3(256), 0, st,
-                           (const double *)tr.p, n, (double)resolution, d, cm->m);
+                           (const double *)tr.p, n, ts, cs, (double)resolution, d, cm->m);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess) e = hipMemcpy(&host_bad, bad.p, sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(host_flags, bad.p, 2 * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && want) e = hipMemcpy(present, pres.p, (size_t)d, hipMemcpyDeviceToHost);
     if (e != hipSuccess)
         return bb::fail(BB_ERR_HIP, std::string("bb_cm_scatter: ") + hipGetErrorString(e));
-    if (host_bad) {
+    if (host_flags[0]) {
         // marks of valid triples may be left in the matrix: clear it, the map is unusable
         (void)hipMemset(cm->m, 0, (size_t)d * d * sizeof(double));
         return bb::fail(BB_ERR_INVALID,
                         "bb_cm_scatter: a position maps to a bin outside [0, n_bins]");
     }
+    if (want) *on_grid = host_flags[1] ? 0 : 1;
     return BB_OK;
+}
+
+int bb_cm_scatter(bb_cm *cm, const double *triples, int64_t n, int32_t resolution) {
+    return bb_cm_scatter_ex(cm, triples, n, resolution, 0, nullptr, nullptr);
 }
 
 int bb_cm_normalize(bb_cm *cm, int64_t n_bins, const double *KRnorm, const double *KRexpected) {

@@ -67,16 +67,39 @@ class _DeviceMatrix(object):
         _lib.check(self._lib.bb_cm_create(self._h, int(d), self.device), "bb_cm_create")
 
     @classmethod
-    def from_triples(cls, triples, resolution, n_bins, device):
+    def from_triples(cls, triples, resolution, n_bins, device, want_regions=False):
+        """Scatter (n, 3) rows [pos_i, pos_j, count].  With want_regions also returns
+        `numpy.union1d(pos_i, pos_j)` (pyx:120): when every position is exactly
+        bin * resolution -- Rao's format -- it is the bins the scatter kernel saw times the
+        resolution (no sort of 2n doubles on the host); otherwise numpy's own union1d."""
+        import ctypes
         t = _nan_to_num(triples)                                            # pyx:102
         if t.ndim != 2 or t.shape[1] != 3:
             raise ValueError("triples must have shape (n, 3)")
-        # the reference's pointer arithmetic reads the array column-major (pyx:111-113)
-        cols = numpy.ascontiguousarray(t.T)
-        self = cls(int(n_bins) + 1, device)                                 # zeros, pyx:99
-        _lib.check(self._lib.bb_cm_scatter(self._h, _lib.as_f64_ptr(cols), t.shape[0],
-                                           int(resolution)), "bb_cm_scatter")
-        return self
+        # C-ordered rows are read in place; the reference's own layout -- pandas hands it
+        # an F-ordered array and its pointer arithmetic reads that column-major
+        # (pyx:111-113) -- is read in place too; anything else is copied once
+        if t.flags.c_contiguous:
+            buf, row_major = t, 1
+        elif t.flags.f_contiguous:
+            buf, row_major = t.T, 0
+        else:
+            buf, row_major = numpy.ascontiguousarray(t), 1
+        d = int(n_bins) + 1
+        self = cls(d, device)                                               # zeros, pyx:99
+        present = numpy.zeros(d, dtype=numpy.uint8)
+        on_grid = _lib.c_i32(0)
+        _lib.check(self._lib.bb_cm_scatter_ex(
+            self._h, _lib.as_f64_ptr(buf), t.shape[0], int(resolution), row_major,
+            present.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.byref(on_grid)),
+            "bb_cm_scatter")
+        if not want_regions:
+            return self
+        if on_grid.value:
+            regions = numpy.flatnonzero(present).astype(numpy.float64) * float(int(resolution))
+        else:
+            regions = numpy.union1d(t[:, 0], t[:, 1])
+        return self, regions
 
     @classmethod
     def from_host(cls, matrix, device):
@@ -155,8 +178,8 @@ class ContactMap(object):
                                header=None).values
         data = _nan_to_num(data)
         self._host = None
-        self._dev = _DeviceMatrix.from_triples(data, self.resolution, self.n_bins, self.device)
-        self.regions = numpy.union1d(data[:, 0], data[:, 1])
+        self._dev, self.regions = _DeviceMatrix.from_triples(data, self.resolution, self.n_bins,
+                                                             self.device, want_regions=True)
         self.regions.sort()
 
     # -- where the matrix lives ------------------------------------------
@@ -275,8 +298,8 @@ class ContactMap(object):
         data = _nan_to_num(triples)
         self.n_bins = int(n_bins)
         self._host = None
-        self._dev = _DeviceMatrix.from_triples(data, self.resolution, self.n_bins, self.device)
-        self.regions = numpy.union1d(data[:, 0], data[:, 1])
+        self._dev, self.regions = _DeviceMatrix.from_triples(data, self.resolution, self.n_bins,
+                                                             self.device, want_regions=True)
         self._KRnorm = None if KRnorm is None else numpy.asarray(KRnorm, dtype=numpy.float64)
         self._KRexpected = (None if KRexpected is None
                             else numpy.asarray(KRexpected, dtype=numpy.float64))

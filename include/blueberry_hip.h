@@ -304,6 +304,15 @@ BB_API int bb_cm_download(bb_cm *cm, double *matrix, int64_t ld);       /* devic
  * (column-major `triples`, as bb_contactmap_scatter) set [j][k] and [k][j]; later
  * triples overwrite earlier ones.  Needs no scratch the size of the matrix. */
 BB_API int bb_cm_scatter(bb_cm *cm, const double *triples, int64_t n, int32_t resolution);
+/* The same with two conveniences for a caller that holds C-ordered rows and wants
+ * `regions` (pyx:120, numpy.union1d of the two position columns) without sorting 2n
+ * doubles: row_major != 0 reads `triples` as (n, 3) rows instead of the reference's
+ * column-major (3, n); `present` (d bytes) receives 1 for every bin some position falls
+ * in and *on_grid 1 if every position equals bin * resolution exactly -- then regions
+ * are the present bins times the resolution, bit for bit.  present / on_grid may both
+ * be NULL. */
+BB_API int bb_cm_scatter_ex(bb_cm *cm, const double *triples, int64_t n, int32_t resolution,
+                            int32_t row_major, uint8_t *present, int32_t *on_grid);
 /* ContactMap.normalize (pyx:161-171), in place: m[j][j+i] /= KRnorm[j]*KRnorm[j+i]*
  * KRexpected[i], mirrored, then nan_to_num over the whole matrix.  d must be n_bins+1. */
 BB_API int bb_cm_normalize(bb_cm *cm, int64_t n_bins, const double *KRnorm,

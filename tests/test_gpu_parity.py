@@ -168,6 +168,44 @@ def test_contactmap_filter_vs_numpy_ragged(d):
         assert cm.n_bins == want.shape[0]
 
 
+@pytest.mark.parametrize("on_grid", [True, False])
+def test_from_triples_layouts_and_regions(on_grid, oracle):
+    """`ContactMap.from_triples` reads C-ordered rows, the reference's F-ordered array
+    (what pandas hands `ContactMap.__init__`, pyx:100-113) and a strided view in place or
+    after one copy -- same matrix, bit for bit the oracle's scatter -- and `regions` equals
+    `numpy.union1d` of the two position columns (pyx:120) both when every position is
+    exactly bin * resolution (taken from the bins the kernel saw) and when some are not
+    (numpy's own union1d)."""
+    rng = numpy.random.default_rng(7 + on_grid)
+    n_bins, res, nnz = 211, 5000, 3000
+    bi = rng.integers(0, n_bins, nnz)
+    bj = rng.integers(0, n_bins + 1, nnz)          # bin n_bins exists too (pyx:97)
+    pos_i = bi * float(res)
+    pos_j = bj * float(res)
+    if not on_grid:
+        pos_i = pos_i + rng.integers(0, res, nnz)   # anywhere inside the bin
+        pos_j[::3] += 1.0
+    rows = numpy.ascontiguousarray(numpy.stack([pos_i, pos_j, rng.integers(1, 90, nnz).astype(float)], 1))
+    want = oracle.contactmap_scatter(rows, res, n_bins)
+    regions = numpy.union1d(rows[:, 0], rows[:, 1])
+    wide = numpy.zeros((nnz, 6)); wide[:, ::2] = rows
+    for layout, arr in (("C", rows), ("F", numpy.asfortranarray(rows)), ("strided", wide[:, ::2])):
+        cm = bb.ContactMap.from_triples(arr, res, n_bins)
+        assert numpy.array_equal(cm.to_host(), want), layout
+        assert cm.regions.dtype == numpy.float64
+        assert numpy.array_equal(cm.regions, regions), layout
+    # the C-ABI's plain entry point still takes the column-major array
+    lib = _lib.load()
+    h = _lib.c_void_p()
+    _lib.check(lib.bb_cm_create(h, n_bins + 1, 0), "create")
+    cols = numpy.ascontiguousarray(rows.T)
+    _lib.check(lib.bb_cm_scatter(h, _lib.as_f64_ptr(cols), nnz, res), "scatter")
+    got = numpy.empty_like(want)
+    _lib.check(lib.bb_cm_download(h, _lib.as_f64_ptr(got), n_bins + 1), "download")
+    lib.bb_cm_destroy(h)
+    assert numpy.array_equal(got, want)
+
+
 @pytest.mark.parametrize("bounce", [1, 7, 1000, 20000])
 def test_contactmap_filter_in_place_bands(bounce, monkeypatch):
     """The filter compacts the resident matrix in place, a band of rows at a time through
