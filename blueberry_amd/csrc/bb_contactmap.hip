@@ -220,32 +220,75 @@ __global__ __launch_bounds__(256) void gather_kernel(const double *__restrict__ 
 }
 
 // ---- eigenvector (datatypes.pyx:216-235): Lanczos on the resident matrix -----------
-// y = M x, one wave per matrix row (4 rows per workgroup): the row is read once, in
-// 512-byte wave loads with kSymvUnroll of them in flight; HBM-bound, 8 B per element.
-constexpr int kSymvUnroll = 8;
+// y = M x.  One wave takes kSymvRows consecutive rows (a workgroup 4 waves), so x is
+// loaded once per kSymvRows row loads, and reads them as 16-byte elements: a row starts on
+// a 16-byte boundary or 8 bytes past one (odd d: every other row), so each row gets its
+// own one-element head and its pairs are {x[2c+o], x[2c+o+1]} with o = 0 or 1.  kSymvUnroll
+// wave loads of 1 KiB per row in flight; fixed summation order; HBM-bound, 8 B per element.
+constexpr int kSymvRows = 4, kSymvUnroll = 4;
 __global__ __launch_bounds__(256) void symv_kernel(const double *__restrict__ m, int64_t d,
                                                    const double *__restrict__ x,
                                                    double *__restrict__ y) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= d) return;
-    const double *p = m + row * d;
-    double acc = 0.0;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kSymvRows;
+    if (row0 >= d) return;
+    const d2 *p2[kSymvRows];
+    int off[kSymvRows];
+    double acc[kSymvRows];
+#pragma unroll
+    for (int r = 0; r < kSymvRows; ++r) {
+        const int64_t row = row0 + r < d ? row0 + r : d - 1;      // a ragged last group re-reads row d-1
+        const double *p = m + row * d;
+        off[r] = (int)((row * d) & 1);
+        p2[r] = reinterpret_cast<const d2 *>(p + off[r]);
+        acc[r] = (off[r] && lane == 0) ? p[0] * x[0] : 0.0;        // the head element
+    }
+    const int64_t n2 = (d - 1) / 2;      // pairs every row has after its head, whatever its o
     int64_t c = lane;
-    for (; c + 64 * (kSymvUnroll - 1) < d; c += 64 * kSymvUnroll) {
-        double a[kSymvUnroll], b[kSymvUnroll];
+    for (; c + 64 * (kSymvUnroll - 1) < n2; c += 64 * kSymvUnroll) {
+        d2 a[kSymvRows][kSymvUnroll];
+        double x0[kSymvUnroll], x1[kSymvUnroll], x2[kSymvUnroll];
 #pragma unroll
         for (int q = 0; q < kSymvUnroll; ++q) {
-            a[q] = __builtin_nontemporal_load(p + c + 64 * q);
-            b[q] = x[c + 64 * q];
+#pragma unroll
+            for (int r = 0; r < kSymvRows; ++r)
+                a[r][q] = __builtin_nontemporal_load(p2[r] + c + 64 * q);
+            const int64_t e = 2 * (c + 64 * q);
+            x0[q] = x[e]; x1[q] = x[e + 1]; x2[q] = x[e + 2];      // e + 2 <= 2 n2 <= d - 1
         }
 #pragma unroll
-        for (int q = 0; q < kSymvUnroll; ++q) acc = fma(a[q], b[q], acc);
-    }
-    for (; c < d; c += 64) acc = fma(p[c], x[c], acc);
+        for (int q = 0; q < kSymvUnroll; ++q)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (lane == 0) y[row] = acc;
+            for (int r = 0; r < kSymvRows; ++r) {
+                acc[r] = fma(a[r][q].x, off[r] ? x1[q] : x0[q], acc[r]);
+                acc[r] = fma(a[r][q].y, off[r] ? x2[q] : x1[q], acc[r]);
+            }
+    }
+    for (; c < n2; c += 64) {
+        const int64_t e = 2 * c;
+#pragma unroll
+        for (int r = 0; r < kSymvRows; ++r) {
+            const d2 v = p2[r][c];
+            acc[r] = fma(v.x, x[e + off[r]], acc[r]);
+            acc[r] = fma(v.y, x[e + off[r] + 1], acc[r]);
+        }
+    }
+    // what is left of a row behind its n2 pairs: elements off + 2 n2 .. d - 1 (at most 2)
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < kSymvRows; ++r) {
+            const int64_t row = row0 + r < d ? row0 + r : d - 1;
+            for (int64_t e = off[r] + 2 * n2; e < d; ++e) acc[r] = fma(m[row * d + e], x[e], acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < kSymvRows; ++r) {
+        double v = acc[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0 && row0 + r < d) y[row0 + r] = v;
+    }
 }
 
 // out[j] = V[j] . w for the basis vectors j < k (one workgroup each); fixed-order sums
@@ -744,7 +787,7 @@ int bb_cm_symv(bb_cm *cm, const double *x, double *y) {
     if (e != hipSuccess) return bb::fail(BB_ERR_NOMEM, std::string("bb_cm_symv: ") + hipGetErrorString(e));
     e = hipMemcpyAsync(dx.p, x, (size_t)d * 8, hipMemcpyHostToDevice, cm->stream);
     if (e == hipSuccess)
-        e = bb::launch(symv_kernel, dim3((unsigned)((d + 3) / 4)), dim3(256), 0, cm->stream,
+        e = bb::launch(symv_kernel, dim3((unsigned)((d + 4 * kSymvRows - 1) / (4 * kSymvRows))), dim3(256), 0, cm->stream,
                        (const double *)cm->m, d, (const double *)dx.p, (double *)dy.p);
     if (e == hipSuccess) e = hipStreamSynchronize(cm->stream);
     if (e == hipSuccess) e = hipMemcpy(y, dy.p, (size_t)d * 8, hipMemcpyDeviceToHost);
@@ -800,7 +843,7 @@ int bb_cm_eigenvector(bb_cm *cm, double *vec, double *eigenvalue, double tol, in
         int k = 0;
         for (; k < m && e == hipSuccess; ++k) {
             // w = M v_k
-            e = bb::launch(symv_kernel, dim3((unsigned)((d + 3) / 4)), b256, 0, st,
+            e = bb::launch(symv_kernel, dim3((unsigned)((d + 4 * kSymvRows - 1) / (4 * kSymvRows))), b256, 0, st,
                            (const double *)cm->m, d, (const double *)(dV + (int64_t)k * d), dw);
             ++used;
             // coefficients against the whole basis (alpha_k is the last one), subtract, and
