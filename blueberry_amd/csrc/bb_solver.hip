@@ -166,10 +166,13 @@ int build_indices(bb_solver *s) {
     if (s->n_local >= ((int64_t)1 << 31))
         return bb::fail(BB_ERR_INVALID, "bb_solver_create: more than 2^31 units on one rank");
     {
-        // non-temporal matrix loads are the default (measured: +2.5 % on the
-        // kernel, +9 % on a pure read sweep); BB_NT=0 turns them off
+        // Matrix loads are non-temporal (measured: +2.5 % on the kernel, +9 % on a pure read
+        // sweep at N=50k) unless this rank's units fit the 256-MB Infinity Cache: then they
+        // are read again from it on the next iteration, and plain loads keep them there
+        // (N=8,000 / 10,000: kernel -8 %, step -3.5 / -6 %; equal at N=12,000 = 288 MB;
+        // non-temporal 3-4 % better at N=17,700; profiles/r02_nt_ab.txt).  BB_NT=0|1 overrides.
         const char *e = getenv("BB_NT");
-        s->nontemporal = !(e && atoi(e) == 0);
+        s->nontemporal = e ? atoi(e) != 0 : s->n_local * bb::kUnitBytes > ((int64_t)240 << 20);
     }
     // wave w owns the contiguous chunk [w*q + min(w, r), +q (+1 if w < r)), q = n_local / nw,
     // r = n_local % nw: the kernels compute it the same way (no table to load)
