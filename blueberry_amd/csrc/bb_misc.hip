@@ -5,7 +5,54 @@
 // in the reference's operation order, NaN behaviour included), pinned by golden vectors.
 #include "bb_common.h"
 
+#include <map>
+#include <mutex>
+
 namespace {
+
+// Per-device scratch kept between calls: a stream and ONE grow-only arena.  A fresh
+// allocation is not what costs -- its first touch is, ~60-70 ms per GB on this platform
+// (tools/alloc_probe.py): a 50 M-element benjamini_hochberg spent more time touching its
+// two new 400-MB buffers than moving them over PCIe.  Arenas above kKeepBytes are given
+// back after the call.  Guarded by a mutex: calls on one device serialise, which is what
+// one stream would do anyway.
+constexpr size_t kKeepBytes = (size_t)1 << 30;
+struct MiscCtx {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    char *arena = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        hipError_t e = hipSuccess;
+        if (!stream) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        if (e == hipSuccess && cap < bytes) {
+            (void)hipFree(arena);
+            arena = nullptr;
+            cap = 0;
+            e = hipMalloc((void **)&arena, bytes);
+            if (e == hipSuccess) cap = bytes;
+        }
+        return e;
+    }
+    void trim() {
+        if (cap > kKeepBytes) {
+            (void)hipFree(arena);
+            arena = nullptr;
+            cap = 0;
+        }
+    }
+};
+MiscCtx *misc_ctx(int device) {
+    static std::mutex table_mu;
+    static std::map<int, MiscCtx *> table;
+    std::lock_guard<std::mutex> lock(table_mu);
+    auto it = table.find(device);
+    if (it != table.end()) return it->second;
+    MiscCtx *c = new MiscCtx();   // lives for the process: freed by the runtime at exit
+    table[device] = c;
+    return c;
+}
+constexpr size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 constexpr int kScanBlock = 256;
 constexpr int kItems = 4;  // per thread -> 1024 elements per workgroup
@@ -181,33 +228,31 @@ int bb_benjamini_hochberg(const double *p_values, int64_t d, int64_t n, double *
     if (d == 0) return BB_OK;
     const int64_t per_block = (int64_t)kScanBlock * kItems;
     const int64_t nblocks = (d + per_block - 1) / per_block;
-    bb::DevBuf p, q, bm, bc, fc;
-    hipStream_t st = nullptr;
-    hipError_t e = p.alloc((size_t)d * 8);
-    if (e == hipSuccess) e = q.alloc((size_t)d * 8);
-    if (e == hipSuccess) e = bm.alloc((size_t)nblocks * 8);
-    if (e == hipSuccess) e = bc.alloc((size_t)nblocks * 4);
-    if (e == hipSuccess) e = fc.alloc((size_t)nblocks * 4);
+    MiscCtx *c = misc_ctx(device);
+    std::lock_guard<std::mutex> lock(c->mu);
+    const size_t o_q = align256((size_t)d * 8), o_bm = o_q + align256((size_t)d * 8),
+                 o_bc = o_bm + align256((size_t)nblocks * 8), o_fc = o_bc + align256((size_t)nblocks * 4),
+                 total = o_fc + align256((size_t)nblocks * 4);
+    hipError_t e = c->ensure(total);
     if (e != hipSuccess)
         return bb::fail(BB_ERR_NOMEM, std::string("bb_benjamini_hochberg: ") + hipGetErrorString(e));
-    e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(p.p, p_values, (size_t)d * 8, hipMemcpyHostToDevice, st);
+    hipStream_t st = c->stream;
+    double *p = (double *)c->arena, *q = (double *)(c->arena + o_q), *bm = (double *)(c->arena + o_bm);
+    int *bc = (int *)(c->arena + o_bc), *fc = (int *)(c->arena + o_fc);
+    e = hipMemcpyAsync(p, p_values, (size_t)d * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         e = bb::launch(bh_local_kernel, dim3((unsigned)nblocks), dim3(kScanBlock), 0, st,
-                       (const double *)p.p, d, (double)n, (double *)q.p, (double *)bm.p,
-                       (int *)bc.p, (int *)fc.p);
+                       (const double *)p, d, (double)n, q, bm, bc, fc);
         if (e == hipSuccess)
-            e = bb::launch(bh_blockscan_kernel, dim3(1), dim3(kScanBlock), 0, st, (double *)bm.p,
-                           (int *)bc.p, nblocks);
+            e = bb::launch(bh_blockscan_kernel, dim3(1), dim3(kScanBlock), 0, st, bm, bc, nblocks);
         if (e == hipSuccess)
-            e = bb::launch(bh_apply_kernel, dim3((unsigned)nblocks), dim3(kScanBlock), 0, st,
-                           (double *)q.p, d, (const double *)bm.p, (const int *)fc.p);
+            e = bb::launch(bh_apply_kernel, dim3((unsigned)nblocks), dim3(kScanBlock), 0, st, q, d,
+                           (const double *)bm, (const int *)fc);
     }
     if (e == hipSuccess)
-        e = hipMemcpyAsync(q_values, q.p, (size_t)d * 8, hipMemcpyDeviceToHost, st);
+        e = hipMemcpyAsync(q_values, q, (size_t)d * 8, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (st) (void)hipStreamDestroy(st);
+    c->trim();
     if (e != hipSuccess)
         return bb::fail(BB_ERR_HIP, std::string("bb_benjamini_hochberg: ") + hipGetErrorString(e));
     return BB_OK;
@@ -219,26 +264,25 @@ int bb_downsample(const float *yp1, int64_t n1, float *yp5i, int64_t n5, int dev
     int rc = bb::use_device(device);
     if (rc != BB_OK) return rc;
     if (n5 < 2) return BB_OK;
-    bb::DevBuf a, b;
-    hipStream_t st = nullptr;
-    hipError_t e = a.alloc((size_t)n1 * n1 * 4);
-    if (e == hipSuccess) e = b.alloc((size_t)n5 * n5 * 4);
+    MiscCtx *c = misc_ctx(device);
+    std::lock_guard<std::mutex> lock(c->mu);
+    const size_t o_b = align256((size_t)n1 * n1 * 4), total = o_b + align256((size_t)n5 * n5 * 4);
+    hipError_t e = c->ensure(total);
     if (e != hipSuccess)
         return bb::fail(BB_ERR_NOMEM, std::string("bb_downsample: ") + hipGetErrorString(e));
-    e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    hipStream_t st = c->stream;
+    float *a = (float *)c->arena, *b = (float *)(c->arena + o_b);
+    e = hipMemcpyAsync(a, yp1, (size_t)n1 * n1 * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess)
-        e = hipMemcpyAsync(a.p, yp1, (size_t)n1 * n1 * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(b.p, yp5i, (size_t)n5 * n5 * 4, hipMemcpyHostToDevice, st);
+        e = hipMemcpyAsync(b, yp5i, (size_t)n5 * n5 * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         const unsigned g = (unsigned)((n5 - 1 + 15) / 16);
-        e = bb::launch(downsample_kernel, dim3(g, g), dim3(256), 0, st, (const float *)a.p, n1,
-                       (float *)b.p, n5);
+        e = bb::launch(downsample_kernel, dim3(g, g), dim3(256), 0, st, (const float *)a, n1, b, n5);
     }
     if (e == hipSuccess)
-        e = hipMemcpyAsync(yp5i, b.p, (size_t)n5 * n5 * 4, hipMemcpyDeviceToHost, st);
+        e = hipMemcpyAsync(yp5i, b, (size_t)n5 * n5 * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (st) (void)hipStreamDestroy(st);
+    c->trim();
     if (e != hipSuccess)
         return bb::fail(BB_ERR_HIP, std::string("bb_downsample: ") + hipGetErrorString(e));
     return BB_OK;
