@@ -42,6 +42,7 @@ struct bb_solver {
     int2 *d_udesc = nullptr;
     int chunk_q = 0, chunk_r = 0;  // units per wave: n_local = n_waves * q + r
     bool nontemporal = true;
+    char *d_arena = nullptr;       // the one allocation behind every d_* below but d_exch / peer / mv_in
     int2 *d_wave_slots = nullptr;  // per wave {first private slot, the workgroup's shared slot}
     int lds_wave_floats = 0;       // LDS region per wave of the sweep, in 4-byte words
     double *d_stresspart = nullptr;
@@ -286,22 +287,6 @@ int build_indices(bb_solver *s) {
     const int64_t part_total = s->part2_off + s->n_slices * ch;
 
     const int64_t es = bb::elem_size(s->dtype);
-    BB_TRY(dev_alloc((char **)&s->d_units, std::max<int64_t>(s->n_local, 1) * bb::kUnitBytes));
-    BB_TRY(dev_alloc((char **)&s->d_X, s->L.n_pad * 3 * es));
-    BB_TRY(dev_alloc((char **)&s->d_V, s->L.n_pad * 3 * es));
-    BB_TRY(dev_alloc((char **)&s->d_part, part_total * es));
-    BB_TRY(dev_alloc(&s->d_udesc, (int64_t)s->udesc.size()));
-    BB_TRY(dev_alloc(&s->d_wave_slots, nw));
-    BB_TRY(dev_alloc(&s->d_stresspart, nw * 9));   // nw partials (+ 8 stamps per wave, diagnostic build)
-    BB_TRY(dev_alloc(&s->d_blk_ptr, nb + 1));
-    BB_TRY(dev_alloc(&s->d_blk_chunk, (int64_t)fin_chunk.size()));
-    BB_TRY(dev_alloc(&s->d_s1_ptr, (int64_t)s1_ptr.size()));
-    BB_TRY(dev_alloc(&s->d_s1_chunk, (int64_t)s1_chunk.size()));
-    BB_TRY(dev_alloc(&s->d_stress_hist, kHistCap));
-    BB_TRY(dev_alloc(&s->d_stress_scalar, 1));
-    BB_TRY(dev_alloc(&s->d_f64_tmp, s->L.n_pad * 3));
-    BB_TRY(dev_alloc((char **)&s->d_exch, (3 * s->L.n_pad + 2) * es));
-    s->own_exch = true;
     s->hist_cap = kHistCap;
     if (s->row_owner) {
         s->full_ld = bb::round_up(s->L.n_bins, kRowTrip);
@@ -312,10 +297,45 @@ int build_indices(bb_solver *s) {
         s->ro_wpr = wpr >= 4 ? 4 : (wpr >= 2 ? 2 : 1);
         const int rows_per_wg = 4 / s->ro_wpr;
         s->ro_blocks = (int)((s->L.n_bins + rows_per_wg - 1) / rows_per_wg);
-        BB_TRY(dev_alloc((char **)&s->d_full, s->L.n_bins * s->full_ld * es));
-        BB_TRY(dev_alloc((char **)&s->d_X2, s->L.n_pad * 3 * es));
-        BB_TRY(dev_alloc(&s->d_ro_part, 2 * (int64_t)s->ro_blocks));
     }
+    {
+        // ONE device allocation for everything the solver owns (the exchange buffer apart:
+        // a caller may replace it).  Twenty hipMalloc + hipFree pairs were 3 of the 4.5 ms a
+        // whole chr21-sized fit took (tools/small_fit_timing.py).
+        std::vector<std::pair<void **, size_t>> want;
+        auto add = [&](auto **ptr, int64_t count) {
+            want.push_back({(void **)ptr, (size_t)std::max<int64_t>(count, 1) * sizeof(**ptr)});
+        };
+        add((char **)&s->d_units, std::max<int64_t>(s->n_local, 1) * bb::kUnitBytes);
+        add((char **)&s->d_X, s->L.n_pad * 3 * es);
+        add((char **)&s->d_V, s->L.n_pad * 3 * es);
+        add((char **)&s->d_part, part_total * es);
+        add(&s->d_udesc, (int64_t)s->udesc.size());
+        add(&s->d_wave_slots, nw);
+        add(&s->d_stresspart, nw * 9);   // nw partials (+ 8 stamps per wave, diagnostic build)
+        add(&s->d_blk_ptr, nb + 1);
+        add(&s->d_blk_chunk, (int64_t)fin_chunk.size());
+        add(&s->d_s1_ptr, (int64_t)s1_ptr.size());
+        add(&s->d_s1_chunk, (int64_t)s1_chunk.size());
+        add(&s->d_stress_hist, kHistCap);
+        add(&s->d_stress_scalar, 1);
+        add(&s->d_f64_tmp, s->L.n_pad * 3);
+        if (s->row_owner) {
+            add((char **)&s->d_full, s->L.n_bins * s->full_ld * es);
+            add((char **)&s->d_X2, s->L.n_pad * 3 * es);
+            add(&s->d_ro_part, 2 * (int64_t)s->ro_blocks);
+        }
+        size_t total = 0;
+        for (auto &w : want) total += (w.second + 255) & ~(size_t)255;
+        BB_TRY(dev_alloc(&s->d_arena, (int64_t)total));
+        size_t off = 0;
+        for (auto &w : want) {
+            *w.first = s->d_arena + off;
+            off += (w.second + 255) & ~(size_t)255;
+        }
+    }
+    BB_TRY(dev_alloc((char **)&s->d_exch, (3 * s->L.n_pad + 2) * es));
+    s->own_exch = true;
 
     hipStream_t st = s->stream;
     BB_HIP_CHECK(hipMemcpyAsync(s->d_udesc, s->udesc.data(), s->udesc.size() * sizeof(int2),
@@ -704,25 +724,9 @@ int bb_solver_destroy(bb_solver *s) {
     hipFree(s->d_peer_state);
     hipFree(s->d_peer_counter);
     for (hipEvent_t e : s->ev) hipEventDestroy(e);
-    hipFree(s->d_units);
-    hipFree(s->d_X);
-    hipFree(s->d_V);
-    hipFree(s->d_part);
+    hipFree(s->d_arena);
     if (s->own_exch) hipFree(s->d_exch);
-    hipFree(s->d_udesc);
-    hipFree(s->d_wave_slots);
-    hipFree(s->d_stresspart);
-    hipFree(s->d_blk_ptr);
-    hipFree(s->d_blk_chunk);
-    hipFree(s->d_s1_ptr);
-    hipFree(s->d_s1_chunk);
-    hipFree(s->d_stress_hist);
-    hipFree(s->d_stress_scalar);
-    hipFree(s->d_f64_tmp);
     hipFree(s->d_mv_in);
-    hipFree(s->d_full);
-    hipFree(s->d_X2);
-    hipFree(s->d_ro_part);
     if (s->own_stream && s->stream) hipStreamDestroy(s->stream);
     delete s;
     // tear-down is best effort (a free can fail when a peer process has already gone
