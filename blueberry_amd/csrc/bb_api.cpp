@@ -2,6 +2,10 @@
 // arithmetic of libblueberry_hip.so (include/blueberry_hip.h).
 #include "bb_common.h"
 
+#include <map>
+#include <mutex>
+#include <vector>
+
 namespace bb {
 
 static thread_local std::string g_last_error;
@@ -28,6 +32,38 @@ int use_device(int device) {
 int enter_device(int device) {
     BB_HIP_CHECK(hipSetDevice(device));
     return BB_OK;
+}
+
+namespace {
+constexpr size_t kPooledStreams = 8;
+std::mutex g_stream_mu;
+std::map<int, std::vector<hipStream_t>> g_streams;
+}  // namespace
+
+hipError_t acquire_stream(int device, hipStream_t *out) {
+    {
+        std::lock_guard<std::mutex> lock(g_stream_mu);
+        auto &v = g_streams[device];
+        if (!v.empty()) {
+            *out = v.back();
+            v.pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void release_stream(int device, hipStream_t stream) {
+    if (!stream) return;
+    if (hipStreamSynchronize(stream) == hipSuccess) {
+        std::lock_guard<std::mutex> lock(g_stream_mu);
+        auto &v = g_streams[device];
+        if (v.size() < kPooledStreams) {
+            v.push_back(stream);
+            return;
+        }
+    }
+    (void)hipStreamDestroy(stream);    // pool full, or the stream is in an error state
 }
 
 }  // namespace bb

@@ -63,6 +63,14 @@ int use_device(int device);
 // thread's sticky "last error" is left alone (see launch() below).
 int enter_device(int device);
 
+// Non-blocking streams are handed out from a small per-device pool: creating one costs
+// 1.3-3 ms and destroying one 1.6 ms on this platform (tools/api_cost_probe.py) -- together
+// two thirds of a whole chr21-sized fit.  acquire gives an idle stream of the CURRENT
+// device (a pooled one, or a new one); release synchronises it and keeps up to
+// kPooledStreams per device for the next handle.
+hipError_t acquire_stream(int device, hipStream_t *out);
+void release_stream(int device, hipStream_t stream);
+
 // Kernel launch that hands back the launch's OWN status (hipLaunchKernel returns it).
 // The library never reads hipGetLastError(): that word is per-thread, sticky, and shared
 // with every other HIP user of the calling thread (torch, RCCL), so a launch check made

@@ -564,7 +564,7 @@ int bb_cm_create(bb_cm **out, int64_t d, int device) {
     cm->device = device;
     cm->d = d;
     hipError_t e = hipMalloc((void **)&cm->m, (size_t)d * d * sizeof(double));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = bb::acquire_stream(device, &cm->stream);
     if (e == hipSuccess) e = hipMemsetAsync(cm->m, 0, (size_t)d * d * sizeof(double), cm->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(cm->stream);
     if (e != hipSuccess) {
@@ -579,10 +579,7 @@ int bb_cm_create(bb_cm **out, int64_t d, int device) {
 int bb_cm_destroy(bb_cm *cm) {
     if (!cm) return BB_OK;
     (void)hipSetDevice(cm->device);
-    if (cm->stream) {
-        (void)hipStreamSynchronize(cm->stream);
-        (void)hipStreamDestroy(cm->stream);
-    }
+    bb::release_stream(cm->device, cm->stream);     // synchronises it
     (void)hipFree(cm->m);
     delete cm;
     (void)hipGetLastError();   // tear-down is best effort; its errors end here

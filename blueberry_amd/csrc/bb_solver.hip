@@ -696,7 +696,7 @@ int bb_solver_create(bb_solver **out, int64_t n_bins, int dtype, int device, int
     }
     if (rc == BB_OK) rc = bb_layout_rank_units(s->L.n_units, rank, world, &s->u_begin, &s->u_end);
     if (rc == BB_OK) {
-        hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+        hipError_t e = bb::acquire_stream(device, &s->stream);
         if (e != hipSuccess)
             rc = bb::fail(BB_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
         else
@@ -727,7 +727,7 @@ int bb_solver_destroy(bb_solver *s) {
     hipFree(s->d_arena);
     if (s->own_exch) hipFree(s->d_exch);
     hipFree(s->d_mv_in);
-    if (s->own_stream && s->stream) hipStreamDestroy(s->stream);
+    if (s->own_stream && s->stream) bb::release_stream(s->device, s->stream);
     delete s;
     // tear-down is best effort (a free can fail when a peer process has already gone
     // away): whatever it left in the thread's error word is consumed here
@@ -739,7 +739,7 @@ int bb_solver_set_stream(bb_solver *s, void *hip_stream) {
     BB_REQUIRE(s != nullptr, "bb_solver_set_stream: solver is NULL");
     BB_TRY(bb::enter_device(s->device));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
-    if (s->own_stream && s->stream) hipStreamDestroy(s->stream);
+    if (s->own_stream && s->stream) bb::release_stream(s->device, s->stream);
     s->stream = (hipStream_t)hip_stream;
     s->own_stream = false;
     return BB_OK;

@@ -11,6 +11,7 @@ handle and, for world_size > 1, drives one all-reduce per iteration through
 torch.distributed (backend "nccl" = RCCL over xGMI).
 """
 import os
+import sys
 
 import numpy
 
@@ -401,12 +402,14 @@ def _dist_state(distributed):
     """(rank, world) of the running torch.distributed job, or (0, 1)."""
     if distributed is False:
         return 0, 1
-    try:
+    if distributed is None:
+        # auto: a process that runs a torch.distributed job has imported it already;
+        # importing torch here just to find that out costs the first fit() 0.7 s
+        dist = sys.modules.get("torch.distributed")
+        if dist is None:
+            return 0, 1
+    else:
         import torch.distributed as dist
-    except ImportError:
-        if distributed:
-            raise
-        return 0, 1
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     if distributed:
