@@ -1176,3 +1176,43 @@ def test_single_bin_is_rejected():
         s = bb.StructureSolver(n_iter=3, lr=0.1, dtype=dtype, kind="wish")
         with pytest.raises(ValueError, match="at least 2 bins"):
             s.fit(numpy.zeros((1, 1)), init=numpy.array([[1.0, 2.0, 3.0]]))
+
+
+@pytest.mark.gpu
+def test_handles_on_concurrent_host_threads():
+    """One handle = one host thread, many handles at once (ctypes releases the GIL
+    per call): four threads each run three whole fits (sweep path and row-owner path, fp32
+    and fp64), a resident ContactMap pipeline and the small helpers, all at the same time,
+    with streams handed out by the library's per-device pool.  Everything is deterministic,
+    so each result must equal, bit for bit, the one the same call gives on its own."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def job(seed):
+        rng = numpy.random.default_rng(seed)
+        out = []
+        for n, dtype in ((300 + 7 * seed, "float64"), (4300 + seed, "float32"), (900, "float32")):
+            xs = numpy.cumsum(rng.standard_normal((n, 3)), axis=0)
+            d = numpy.sqrt(((xs[:, None, :] - xs[None, :, :]) ** 2).sum(-1))
+            x0 = xs + 0.3 * rng.standard_normal(xs.shape)
+            s = bb.StructureSolver(n_iter=12, dtype=dtype, kind="wish", distributed=False).fit(d, init=x0)
+            out.append((s.structure_.copy(), s.stress_.copy()))
+        n_bins, res = 150 + seed, 1000
+        tr = numpy.stack([rng.integers(0, n_bins, 900) * float(res), rng.integers(0, n_bins, 900) * float(res),
+                          rng.integers(1, 50, 900).astype(float)], 1)
+        cm = bb.ContactMap.from_triples(tr, res, n_bins, KRnorm=0.5 + rng.random(n_bins),
+                                        KRexpected=0.5 + rng.random(n_bins))
+        cm.normalize()
+        cm.filter(0.0)
+        out.append((cm.to_host(), cm.regions.copy()))
+        r = numpy.sort(rng.integers(0, 3000, 700) * 5000.0)
+        out.append((numpy.array([bb.count_band_regions(r)]),
+                    bb.benjamini_hochberg(numpy.sort(rng.random(5000)), 5000)))
+        return out
+
+    seeds = [1, 2, 3, 4]
+    alone = [job(s) for s in seeds]
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        together = list(pool.map(job, seeds))
+    for a, b in zip(alone, together):
+        for (a0, a1), (b0, b1) in zip(a, b):
+            assert numpy.array_equal(a0, b0, equal_nan=True) and numpy.array_equal(a1, b1, equal_nan=True)
