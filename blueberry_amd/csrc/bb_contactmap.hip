@@ -742,8 +742,8 @@ int bb_cm_filter(bb_cm *cm, double threshold, int64_t *d_new, uint8_t *keep_out)
     // Compaction IN PLACE, a band of rows at a time through a small bounce buffer: the
     // new matrix is the old one read in order with elements left out, so new row r lands at
     // [r dn, (r+1) dn), in front of every element a later row still needs (those start at
-    // old_row(r+1) d >= (r+1) dn).  No matrix-sized allocation: a fresh hipMalloc of 1-5 GB
-    // costs 170-350 ms on this platform (tools/alloc_probe.py), the whole filter 3 ms.
+    // old_row(r+1) d >= (r+1) dn).  No matrix-sized allocation: the first touch of a fresh
+    // 1-5 GB block costs 170-350 ms on this platform (tools/alloc_probe.py), the whole filter 3 ms.
     // The buffer keeps its size; only d shrinks.
     if (dn > 0 && dn < d) {
         // BB_CM_FILTER_BOUNCE (elements): tests shrink the bounce buffer so that small
