@@ -1216,3 +1216,41 @@ def test_handles_on_concurrent_host_threads():
     for a, b in zip(alone, together):
         for (a0, a1), (b0, b1) in zip(a, b):
             assert numpy.array_equal(a0, b0, equal_nan=True) and numpy.array_equal(a1, b1, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_contactmap_stage_at_chr1_10kb_size(oracle):
+    """A2 / A3 / A4 at BASELINE config 3's real size (n_bins = 24,926: a 4.97 GB matrix)
+    against the CPU oracle's restatement of the reference loops and numpy, bit for bit:
+    scatter of 3 M triples with repeated pairs (pyx:110-116, last one wins), normalize
+    (pyx:161-171), marginals (`matrix.sum(axis=0)`, pyx:140) and filter at the median
+    marginal -- each compared on the whole matrix, which stays resident in between."""
+    n_bins, res, nnz = 24926, 10000, 3_000_000
+    rng = numpy.random.default_rng(24926)
+    bi = rng.integers(0, n_bins, nnz)
+    bj = numpy.minimum(n_bins - 1, bi + rng.geometric(0.01, nnz))
+    rows = numpy.stack([bi * float(res), bj * float(res), rng.integers(1, 500, nnz).astype(float)], 1)
+    rows[nnz // 2:nnz // 2 + 50000, :2] = rows[:50000, :2]          # repeated pairs
+    kr = 0.5 + rng.random(n_bins)
+    kr[::997] = numpy.nan                                            # NaN KR entries (0/0 -> 0)
+    ke = 50.0 / (1.0 + numpy.arange(n_bins)) + 0.1
+    cm = bb.ContactMap.from_triples(rows, res, n_bins, KRnorm=kr, KRexpected=ke)
+    dev = cm._resident()
+    want = oracle.contactmap_scatter(rows, res, n_bins)
+    assert numpy.array_equal(dev.to_host(), want)
+    assert numpy.array_equal(cm.regions, numpy.union1d(rows[:, 0], rows[:, 1]))
+    cm.normalize()
+    want = oracle.contactmap_normalize(want, kr, ke)
+    got = dev.to_host()
+    assert numpy.array_equal(got, want)
+    del got
+    marg = want.sum(axis=0)
+    assert numpy.array_equal(cm.marginals(), marg)
+    thr = float(numpy.median(marg))
+    cm.filter(thr)
+    keep = marg > thr
+    assert cm.is_resident and cm.shape == (int(keep.sum()),) * 2
+    got = cm._resident().to_host()
+    kept = numpy.flatnonzero(keep)
+    for lo in range(0, got.shape[0], 2048):                          # row slabs: bounded host memory
+        assert numpy.array_equal(got[lo:lo + 2048], want[kept[lo:lo + 2048]][:, keep])
