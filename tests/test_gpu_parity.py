@@ -360,6 +360,16 @@ def test_contactmap_handle_error_behaviour():
     assert lib.bb_cm_download(h, _lib.as_f64_ptr(m), 5) == _lib.BB_OK
     assert not m.any()                                                      # the map was cleared
     assert lib.bb_cm_scatter(h, _lib.as_f64_ptr(tr), 1, 0) == _lib.BB_ERR_INVALID     # resolution 0
+    pres = numpy.zeros(5, dtype=numpy.uint8)
+    og = _lib.c_i32(7)
+    ok = numpy.array([1000.0, 3000.0, 2.0])                                 # one row: bins 1 and 3
+    assert lib.bb_cm_scatter_ex(h, _lib.as_f64_ptr(ok), 1, 1000, 1, pres.ctypes.data_as(u8),
+                                ctypes.cast(None, ctypes.POINTER(_lib.c_i32))) == _lib.BB_ERR_INVALID
+    assert b"go together" in lib.bb_last_error()                            # present without on_grid
+    assert lib.bb_cm_scatter_ex(h, _lib.as_f64_ptr(ok), 1, 1000, 1, pres.ctypes.data_as(u8),
+                                ctypes.byref(og)) == _lib.BB_OK
+    assert pres.tolist() == [0, 1, 0, 1, 0] and og.value == 1
+    assert lib.bb_cm_scatter(h, _lib.as_f64_ptr(tr), 1, 1000) == _lib.BB_ERR_INVALID  # clears it again
     assert lib.bb_cm_upload(h, _lib.as_f64_ptr(m), 4) == _lib.BB_ERR_INVALID          # ld < d
     assert lib.bb_cm_filter(h, 0.0, d, ctypes.cast(None, u8)) == _lib.BB_OK and d.value == 0
     assert lib.bb_cm_dim(h, d) == _lib.BB_OK and d.value == 0               # nothing survives: 0 x 0
