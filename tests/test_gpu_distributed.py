@@ -91,6 +91,69 @@ def test_ranks_share_one_gpu(dtype, tol, world, comm):
         assert numpy.array_equal(results[0][2], r[2])
 
 
+def _worker_genome(rank, world, port, n, k, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["BB_COMM"] = "peer"
+        os.environ["BB_PEER_TIMEOUT_MS"] = "20000"
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from blueberry_amd.solver import HipEngine, run_iterations
+        from tests import _oracle
+        xs = _oracle.random_walk(n)
+        eng = HipEngine(n, "float32", rank=rank, world=world, device=0)
+        eng.set_wish_from_coords(xs)           # this rank's share, generated on the device
+        eng.set_coords(_oracle.noisy_init(xs))
+        run_iterations(eng, k, 1.0 / (2 * n), world)
+        eng.sync()
+        eng.peer_status()
+        q.put((rank, eng.get_coords(), eng.stress_history(), eng._comm_state))
+        dist.barrier()
+        eng.close()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, traceback.format_exc(), None, None))
+
+
+def test_config4_size_two_ranks_over_the_peer_exchange():
+    """BASELINE config 4 at its real size (N = 61,914 bins fp32, 7.67 GB of units) with the
+    multi-rank path proper: two processes, each holding half of the units, summing their
+    partial gradients through the in-kernel peer exchange (IPC arenas; the two share the one
+    GPU of the test box) -- against the same iterations on one rank, within the config's
+    1e-5, and bit-identical between the ranks."""
+    import torch.multiprocessing as mp
+    from blueberry_amd.solver import HipEngine
+    from tests import _oracle
+    n, k, world = 61914, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_genome, args=(r, world, port, n, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=400) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert not isinstance(r[1], str), r[1]
+        assert r[3] == "peer"
+    xs = _oracle.random_walk(n)
+    one = HipEngine(n, "float32")
+    one.set_wish_from_coords(xs)
+    one.set_coords(_oracle.noisy_init(xs))
+    one.iterate(k, 1.0 / (2 * n))
+    X1, h1 = one.get_coords(), one.stress_history()
+    one.close()
+    for rank, X, hist, _ in results:
+        assert numpy.abs(X - X1).max() < 1e-5 * numpy.abs(X1).max()
+        assert numpy.abs(hist / h1 - 1).max() < 1e-5
+    assert numpy.array_equal(results[0][1], results[1][1])
+    assert numpy.array_equal(results[0][2], results[1][2])
+    assert h1[-1] < h1[0]
+
+
 def _peer_engines(world, n, dtype, wish, x0, mu=0.0):
     """`world` ranks inside this process, one HipEngine (own stream) each, their
     receive arenas connected directly (same-process shortcut of peer_connect)."""
