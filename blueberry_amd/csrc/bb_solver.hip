@@ -1246,7 +1246,7 @@ int bb_solver_iterate_peer(bb_solver *s, int64_t iters, double lr) {
         return bb::fail(BB_ERR_STATE, "bb_solver_iterate_peer: stress history full");
     BB_TRY(bb::enter_device(s->device));
     const int64_t n3 = s->L.n_pad * 3, es = bb::elem_size(s->dtype);
-    const unsigned grid = (unsigned)((n3 + 255) / 256);
+    const unsigned grid = (unsigned)std::min<int64_t>((n3 + 255) / 256, kPeerReceiveWGs);
     for (int64_t k = 0; k < iters; ++k) {
         hipEvent_t *ev = timing_slot(s);
         if (ev) BB_HIP_CHECK(hipEventRecord(ev[0], s->stream));

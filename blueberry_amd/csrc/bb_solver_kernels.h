@@ -1184,28 +1184,49 @@ __global__ __launch_bounds__(256) void peer_receive_kernel(
     if (!go) return;
     // The arena is read with system-scope loads, which go past L1/L2 to memory: issued
     // after the barrier they cannot be older than the flags wave 0 acquired.
-    const int64_t e = (int64_t)blockIdx.x * 256 + tid;
-    if (e < n3) {
-        // all slots are requested before the first add (one memory round trip per
-        // eight ranks, not one per rank); the sum itself runs in rank order
-        T g = T(0);
+    // The grid is capped (kPeerReceiveWGs workgroups, a thread takes several elements): a
+    // grid the size of the update would fill every wave slot of the device with waves that
+    // spin, and when several ranks share one GPU -- the test box, a rehearsal -- the kernel of
+    // the rank they wait for could then not start at all (found by the four-rank test at
+    // N=309,568: 3,629 workgroups waiting, nobody delivering, time-out).
+    constexpr int EPT = 4;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t base = (int64_t)blockIdx.x * 256 + tid; base < n3; base += EPT * stride) {
+        // all slots of all of the thread's elements are requested before the first add (one
+        // memory round trip per eight ranks, not one per rank and element); the sum of an
+        // element runs in rank order
+        T g[EPT];
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) g[q] = T(0);
         for (int r0 = 0; r0 < world; r0 += 8) {
-            T v[8];
+            T v[EPT][8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                v[q] = r0 + q < world
-                           ? __hip_atomic_load(arena + (r0 + q) * slot_elems + e, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_SYSTEM)
-                           : T(0);
+            for (int q = 0; q < EPT; ++q) {
+                const int64_t e = base + q * stride;
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (r0 + q < world) g += v[q];
+                for (int p = 0; p < 8; ++p)
+                    v[q][p] = (e < n3 && r0 + p < world)
+                                  ? __hip_atomic_load(arena + (r0 + p) * slot_elems + e,
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                  : T(0);
+            }
+#pragma unroll
+            for (int q = 0; q < EPT; ++q)
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+                    if (r0 + p < world) g[q] += v[q][p];
         }
-        const T v = mu * V[e] - lr * g;
-        V[e] = v;
-        X[e] += v;
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int64_t e = base + q * stride;
+            if (e < n3) {
+                const T vv = mu * V[e] - lr * g[q];
+                V[e] = vv;
+                X[e] += vv;
+            }
+        }
     }
-    if (e == 0) {
+    if (blockIdx.x == 0 && tid == 0) {
         double S = 0.0;
         for (int r = 0; r < world; ++r)
             S += (double)__hip_atomic_load(arena + r * slot_elems + n3, __ATOMIC_RELAXED,
@@ -1215,6 +1236,7 @@ __global__ __launch_bounds__(256) void peer_receive_kernel(
         *stress_out = S;
     }
 }
+constexpr unsigned kPeerReceiveWGs = 256;
 
 template <typename T>
 __global__ __launch_bounds__(256) void apply_kernel(T *__restrict__ X, T *__restrict__ V,

@@ -117,6 +117,78 @@ def _worker_genome(rank, world, port, n, k, q):
         q.put((rank, traceback.format_exc(), None, None))
 
 
+def _band_tiles(n, vw=512, width=2):
+    nb = -(-n // vw)
+    tj, ti = numpy.meshgrid(numpy.arange(nb), numpy.arange(nb))
+    sel = (ti <= tj) & (tj - ti <= width)
+    order = numpy.lexsort((ti[sel], tj[sel]))
+    return ti[sel][order].astype(numpy.int32), tj[sel][order].astype(numpy.int32)
+
+
+def _worker_band(rank, world, port, n, k, lr, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["BB_COMM"] = "peer"
+        os.environ["BB_PEER_TIMEOUT_MS"] = "20000"
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from blueberry_amd.solver import HipEngine, run_iterations
+        from tests import _oracle
+        xs = _oracle.random_walk(n)
+        eng = HipEngine(n, "float32", rank=rank, world=world, device=0, tiles=_band_tiles(n))
+        eng.set_wish_from_coords(xs)
+        eng.set_coords(_oracle.noisy_init(xs))
+        run_iterations(eng, k, lr, world)
+        eng.sync()
+        eng.peer_status()
+        q.put((rank, eng.get_coords(), eng.stress_history(), eng._comm_state))
+        dist.barrier()
+        eng.close()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, traceback.format_exc(), None, None))
+
+
+def test_config5_shape_four_ranks_over_the_peer_exchange():
+    """BASELINE config 5's shape at its real size (N = 309,568 bins, fp32, blocked-sparse:
+    the tiles within two tile-diagonals of the main one) on FOUR ranks -- four processes
+    sharing the test box's GPU, partial gradients of 929 k coordinates summed through the
+    peer exchange every iteration -- against the same iterations on one rank (1e-5), the
+    ranks bit-identical among themselves."""
+    import torch.multiprocessing as mp
+    from blueberry_amd.solver import HipEngine
+    from tests import _oracle
+    n, k, world = 309568, 4, 4
+    lr = 1.0 / (2 * 3 * 512)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_band, args=(r, world, port, n, k, lr, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=400) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert not isinstance(r[1], str), r[1]
+        assert r[3] == "peer"
+    xs = _oracle.random_walk(n)
+    one = HipEngine(n, "float32", tiles=_band_tiles(n))
+    one.set_wish_from_coords(xs)
+    one.set_coords(_oracle.noisy_init(xs))
+    one.iterate(k, lr)
+    X1, h1 = one.get_coords(), one.stress_history()
+    one.close()
+    for rank, X, hist, _ in results:
+        assert numpy.abs(X - X1).max() < 1e-5 * numpy.abs(X1).max()
+        assert numpy.abs(hist / h1 - 1).max() < 1e-5
+    for r in results[1:]:
+        assert numpy.array_equal(results[0][1], r[1]) and numpy.array_equal(results[0][2], r[2])
+    assert (numpy.diff(h1) < 0).all()
+
+
 def test_config4_size_two_ranks_over_the_peer_exchange():
     """BASELINE config 4 at its real size (N = 61,914 bins fp32, 7.67 GB of units) with the
     multi-rank path proper: two processes, each holding half of the units, summing their
