@@ -974,6 +974,7 @@ struct PeerState {
     int status;
     int pad;
     unsigned long long verdict;
+    unsigned long long decided;   // sequence number of the last launch whose wait has ended, either way
 };
 // Flag value a failed rank leaves on every peer: their waits end at once and fail too.
 constexpr unsigned long long kPeerPoison = ~0ull;
@@ -1153,30 +1154,29 @@ __global__ __launch_bounds__(256) void peer_receive_kernel(
             }
             if (all_ok) {
                 if (lane == 0)
-                    __hip_atomic_store(&state->verdict, seq, __ATOMIC_RELEASE,
+                    __hip_atomic_store(&state->verdict, seq, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 if (lane < world)
                     __hip_atomic_store(poison_flags[lane], kPeerPoison, __ATOMIC_RELEASE,
                                        __HIP_MEMORY_SCOPE_SYSTEM);
                 if (lane == 0)
-                    __hip_atomic_store(&state->status, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&state->status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            // one word says "this launch's wait is over": what the other workgroups poll
+            if (lane == 0)
+                __hip_atomic_store(&state->decided, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             // ends when workgroup 0 has decided, one way or the other (it always does:
             // its own wait is bounded)
-            // (relaxed polls and ONE acquire fence at the end: an acquire is a cache
-            // invalidate on this part, and 200 waves issuing one per poll cost 12 us)
-            for (;;) {
-                const unsigned long long vd =
-                    __hip_atomic_load(&state->verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int st =
-                    __hip_atomic_load(&state->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (vd == seq) { all_ok = true; break; }
-                if (st != 0) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
+            // (relaxed polls of ONE word, well apart, and ONE acquire fence at the end: an
+            // acquire is a cache invalidate on this part -- 200 waves issuing one per poll
+            // cost 12 us -- and a thousand waves hammering one line leave little of its
+            // memory channel to the ranks that share the device in a rehearsal)
+            while (__hip_atomic_load(&state->decided, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq)
+                __builtin_amdgcn_s_sleep(32);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            all_ok = __hip_atomic_load(&state->verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq;
         }
         if (tid == 0) go = all_ok ? 1 : 0;
     }
