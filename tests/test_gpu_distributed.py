@@ -55,16 +55,20 @@ def _worker(rank, world, port, n, k, dtype, q, comm="host"):
         q.put((rank, traceback.format_exc(), None, None))
 
 
-@pytest.mark.parametrize("dtype,tol,world,comm", [
-    ("float64", 1e-12, 2, "host"), ("float32", 1e-5, 2, "host"),
+@pytest.mark.parametrize("dtype,tol,world,comm,n", [
+    ("float64", 1e-12, 2, "host", 1300), ("float32", 1e-5, 2, "host", 1300),
     # the peer exchange between real processes: arenas mapped through HIP IPC,
     # flags and partials written by the other process's kernels
-    ("float64", 1e-12, 2, "peer"), ("float32", 1e-5, 2, "peer"), ("float32", 1e-5, 4, "peer")])
-def test_ranks_share_one_gpu(dtype, tol, world, comm):
+    ("float64", 1e-12, 2, "peer", 1300), ("float32", 1e-5, 2, "peer", 1300),
+    ("float32", 1e-5, 4, "peer", 1300),
+    # fp64 above 4096 bins: the 2 x 512 units (MFMA row reduction, parked row sums), an odd
+    # number of ranks, heavy-ball momentum
+    ("float64", 1e-12, 3, "peer", 7000)])
+def test_ranks_share_one_gpu(dtype, tol, world, comm, n):
     import torch.multiprocessing as mp
     import blueberry_amd as bb
     from tests import _oracle
-    n, k = 1300, 5
+    k = 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
