@@ -764,8 +764,8 @@ def select_exchange(eng, lr, trial=False):
             if set_limit:
                 set_limit(_TRIAL_PEER_TIMEOUT_MS)
             runs = {}
-            for name, step in (("rccl", eng.iterate_dist), ("peer", eng.iterate_peer)):
-                runs[name] = _trial_leg(eng, name, step, lr, x0, 10)
+
+            def abort_if_failed(name):
                 if name == "rccl" and not runs[name][0] and hasattr(eng, "comm_abort"):
                     # the library's communicator is suspect (this rank may still sit in a
                     # collective a peer never joined): abort it -- every rank does,
@@ -775,6 +775,21 @@ def select_exchange(eng, lr, trial=False):
                     except Exception as exc:
                         eng._comm_trial_error = "%s; abort: %s" % (
                             getattr(eng, "_comm_trial_error", None), exc)
+
+            for name, step in (("rccl", eng.iterate_dist), ("peer", eng.iterate_peer)):
+                runs[name] = _trial_leg(eng, name, step, lr, x0, 10)
+                abort_if_failed(name)
+            if runs["rccl"][0] and runs["peer"][0]:
+                # the leg that runs first is timed on a chip whose clocks have not settled
+                # (a block right after idle runs 4-19 % slow): RCCL gets a
+                # second timing behind the peer leg and keeps its better one.  (Leg outcomes
+                # are agreed between the ranks, so every rank takes this branch or none.)
+                again = _trial_leg(eng, "rccl", eng.iterate_dist, lr, x0, 10)
+                if again[0]:
+                    runs["rccl"] = (True, runs["rccl"][1], min(runs["rccl"][2], again[2]))
+                else:
+                    runs["rccl"] = (False, None, float("inf"))
+                    abort_if_failed("rccl")
             if set_limit and runs["peer"][0]:
                 set_limit(int(os.environ.get("BB_PEER_TIMEOUT_MS", "10000")))
             eng.set_coords(x0)
