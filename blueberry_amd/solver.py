@@ -665,7 +665,7 @@ _TRIAL_SYNC_TIMEOUT_MS = int(os.environ.get("BB_TRIAL_SYNC_TIMEOUT_MS", "30000")
 
 def _trial_leg(eng, name, step, lr, x0, iters):
     """One transport's trial run from the start x0: one step (coordinates kept for the
-    agreement check), three more to warm up, `iters` timed.  After EVERY stage the ranks
+    agreement check), ten more to warm up, `iters` timed.  After EVERY stage the ranks
     agree on whether all of them got through it; the first stage that failed anywhere
     ends the leg on every rank, so nobody enters a collective that a peer has left.
     Returns (ok, coordinates after one step, seconds per iteration)."""
@@ -699,7 +699,7 @@ def _trial_leg(eng, name, step, lr, x0, iters):
         box["x1"] = eng.get_coords()
 
     def warm():
-        step(3, lr)
+        step(10, lr)
         settle()
 
     def timed():
@@ -777,14 +777,14 @@ def select_exchange(eng, lr, trial=False):
                             getattr(eng, "_comm_trial_error", None), exc)
 
             for name, step in (("rccl", eng.iterate_dist), ("peer", eng.iterate_peer)):
-                runs[name] = _trial_leg(eng, name, step, lr, x0, 10)
+                runs[name] = _trial_leg(eng, name, step, lr, x0, 30)
                 abort_if_failed(name)
             if runs["rccl"][0] and runs["peer"][0]:
                 # the leg that runs first is timed on a chip whose clocks have not settled
                 # (a block right after idle runs 4-19 % slow): RCCL gets a
                 # second timing behind the peer leg and keeps its better one.  (Leg outcomes
                 # are agreed between the ranks, so every rank takes this branch or none.)
-                again = _trial_leg(eng, "rccl", eng.iterate_dist, lr, x0, 10)
+                again = _trial_leg(eng, "rccl", eng.iterate_dist, lr, x0, 30)
                 if again[0]:
                     runs["rccl"] = (True, runs["rccl"][1], min(runs["rccl"][2], again[2]))
                 else:
@@ -801,7 +801,9 @@ def select_exchange(eng, lr, trial=False):
             dist.all_gather_object(every, mine)
             t_rccl = max(e[1] for e in every)
             t_peer = max(e[2] for e in every)
-            use_peer = all(e[0] for e in every) and t_peer < t_rccl
+            # the library communicator is the plain path: the peer exchange has to win by
+            # more than the trial's own noise (3 %), not by a coin flip
+            use_peer = all(e[0] for e in every) and t_peer < 0.97 * t_rccl
             ms = lambda t: t * 1e3 if numpy.isfinite(t) else None
             eng._comm_trial = {"agree": all(e[0] for e in every), "rccl_ms": ms(t_rccl),
                                "peer_ms": ms(t_peer),
