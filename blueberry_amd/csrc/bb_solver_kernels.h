@@ -967,9 +967,10 @@ struct PeerTable {
 // Health of this rank's peer exchange, in device memory.  `status` is sticky: once a
 // wait has failed (time limit, or a peer reported its own failure) every later launch
 // of this rank leaves X alone and pushes nothing.  `verdict` is the sequence number of
-// the last exchange whose R partials all arrived: written by ONE wave
-// (peer_wait_kernel), read by every workgroup of the update, so a launch is applied
-// by all of its workgroups or by none.
+// the last exchange whose R partials all arrived, `decided` that of the last launch whose
+// wait has ended either way: both written by ONE wave (the first of peer_receive_kernel);
+// the other workgroups of that launch poll `decided`, then read `verdict`, so a step is
+// applied by all of its workgroups or by none.
 struct PeerState {
     int status;
     int pad;
