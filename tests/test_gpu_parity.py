@@ -1264,3 +1264,39 @@ def test_contactmap_stage_at_chr1_10kb_size(oracle):
     kept = numpy.flatnonzero(keep)
     for lo in range(0, got.shape[0], 2048):                          # row slabs: bounded host memory
         assert numpy.array_equal(got[lo:lo + 2048], want[kept[lo:lo + 2048]][:, keep])
+
+
+@pytest.mark.gpu
+def test_triples_paths_agree_at_genome_50kb_size():
+    """BASELINE config 4's size (61,914 bins: 3.8e9 matrix cells, past 2^31) through the two
+    device paths from Rao-format triples: the resident `ContactMap` (scatter -> normalize ->
+    device-to-device pack: a 30.7 GB fp64 matrix in HBM) and `fit_triples` (entries scattered
+    straight into the solver's blocked-sparse tiles, KR / O-E on the way, no dense matrix).
+    Same triples, same start, three iterations in fp32: the stress histories and the
+    coordinates agree to 1e-5 -- any 32-bit index that wrapped in either path would not."""
+    n_bins, res, nnz, k = 61914, 50000, 4_000_000, 3
+    rng = numpy.random.default_rng(61914)
+    bi = rng.integers(0, n_bins, nnz)
+    bj = numpy.minimum(n_bins - 1, bi + rng.geometric(0.003, nnz))
+    bj[:1000] = n_bins - 1 - rng.integers(0, 50, 1000)            # cells in the far corner too
+    bi[:1000] = n_bins - 60 - rng.integers(0, 50, 1000)
+    key = numpy.unique(bi * n_bins + bj)                            # each bin pair once
+    bi, bj = key // n_bins, key % n_bins
+    triples = numpy.stack([bi * float(res), bj * float(res),
+                           rng.integers(1, 400, bi.size).astype(float)], 1)
+    kr = 0.5 + rng.random(n_bins)
+    ke = 40.0 / (1.0 + numpy.arange(n_bins)) + 0.2
+    n = n_bins + 1
+    x0 = numpy.cumsum(numpy.random.default_rng(1).standard_normal((n, 3)), axis=0)
+    lr = 1.0 / (2 * 400)                                            # few hundred constraints per bin
+    cm = bb.ContactMap.from_triples(triples, res, n_bins, KRnorm=kr, KRexpected=ke)
+    cm.normalize()
+    dense = bb.StructureSolver(n_iter=k, lr=lr, dtype="float32", distributed=False).fit(cm, init=x0)
+    assert cm.is_resident
+    del cm
+    direct = bb.StructureSolver(n_iter=k, lr=lr, dtype="float32", distributed=False).fit_triples(
+        triples, res, n_bins, KRnorm=kr, KRexpected=ke, init=x0)
+    assert numpy.isfinite(dense.stress_).all() and dense.stress_[0] > 0
+    assert numpy.abs(direct.stress_ / dense.stress_ - 1).max() < 1e-5
+    assert _rel(direct.structure_, dense.structure_) < 1e-5
+    assert dense.stress_[-1] < dense.stress_[0]
