@@ -11,9 +11,9 @@
 namespace {
 
 // Per-device scratch kept between calls: a stream and ONE grow-only arena.  A fresh
-// allocation is not what costs -- its first touch is, ~60-70 ms per GB on this platform
-// (tools/alloc_probe.py): a 50 M-element benjamini_hochberg spent more time touching its
-// two new 400-MB buffers than moving them over PCIe.  Arenas above kKeepBytes are given
+// allocation is not what costs -- the first use of a freshly mapped block is, 0.17-0.35 s on
+// this platform (tools/alloc_probe.py), and a stream costs 3-4 ms to make and destroy:
+// small calls spent 3 ms around 0.1 ms of work.  Arenas above kKeepBytes are given
 // back after the call.  Guarded by a mutex: calls on one device serialise, which is what
 // one stream would do anyway.
 constexpr size_t kKeepBytes = (size_t)1 << 30;
