@@ -156,7 +156,9 @@ BB_API int bb_solver_get_coords(bb_solver *s, double *xyz);
 BB_API int bb_solver_set_momentum(bb_solver *s, double mu);
 
 /* world = 1: `iters` iterations of { stress + gradient, update }, enqueued
- * back to back; stress history is kept on the device. */
+ * back to back; stress history is kept on the device (2^20 entries: more iterations than
+ * that since the last bb_solver_set_coords are refused with BB_ERR_STATE before anything is
+ * enqueued -- read the history out and set the coordinates again to go on). */
 BB_API int bb_solver_iterate(bb_solver *s, int64_t iters, double lr);
 
 /* world > 1 (also valid for world = 1): one iteration in two halves around

@@ -1025,6 +1025,9 @@ def test_solver_state_machine():
     s_a = e.stress()
     assert e.stress() == s_a and e.stress_history().shape == (0,)     # no side effects
     assert numpy.array_equal(e.get_coords(), x0)
+    with pytest.raises(RuntimeError, match="history"):
+        e.iterate((1 << 20) + 1, 1.0 / (2 * n))        # more than the device history holds: refused whole
+    assert e.stress_history().shape == (0,) and numpy.array_equal(e.get_coords(), x0)
     e.iterate(3, 1.0 / (2 * n))
     h = e.stress_history()
     # (the stress-only sweep runs over the units, iterate() on the row-owner path at this
