@@ -473,6 +473,9 @@ class StructureSolver(object):
             raise ValueError("kind must be 'counts' or 'wish'")
         if int(n_iter) < 0:
             raise ValueError("n_iter must be >= 0")
+        if int(n_iter) > (1 << 20):
+            raise ValueError("n_iter is limited to 2**20: the per-iteration stress history "
+                             "lives on the device (include/blueberry_hip.h, bb_solver_iterate)")
         if not (lr == "auto" or float(lr) > 0):
             raise ValueError("lr must be positive or 'auto'")
         if not float(alpha) > 0:

@@ -360,3 +360,10 @@ def test_bench_self_launch_relays_rank0_line(tmp_path):
     r = subprocess.run([sys.executable, str(fake), "--gpus", "2", "--steps", "13"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0                                       # a rank's failure is relayed
+
+
+def test_n_iter_beyond_the_device_history_is_refused_up_front():
+    import blueberry_amd as bb
+    with pytest.raises(ValueError, match="2\\*\\*20"):
+        bb.StructureSolver(n_iter=(1 << 20) + 1)
+    bb.StructureSolver(n_iter=1 << 20)
