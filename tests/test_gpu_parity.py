@@ -1303,3 +1303,20 @@ def test_triples_paths_agree_at_genome_50kb_size():
     assert numpy.abs(direct.stress_ / dense.stress_ - 1).max() < 1e-5
     assert _rel(direct.structure_, dense.structure_) < 1e-5
     assert dense.stress_[-1] < dense.stress_[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_early_stop_on_the_device_paths(dtype, solver_path):
+    """`tol`: the loop ends at the first check (every `check_every` steps) where one step's
+    relative stress decrease is <= tol; what was run is a prefix of the full run, bit for
+    bit, on the row-owner path and on the unit sweep."""
+    n = 700
+    xs, w, x0 = _problem(n)
+    kw = dict(dtype=dtype, kind="wish", distributed=False)
+    full = bb.StructureSolver(n_iter=120, **kw).fit(w, init=x0)
+    early = bb.StructureSolver(n_iter=120, tol=0.3, check_every=4, **kw).fit(w, init=x0)
+    assert full.n_iter_ == 120 and 4 <= early.n_iter_ < 120 and early.n_iter_ % 4 == 0
+    assert numpy.array_equal(early.stress_, full.stress_[:early.n_iter_])
+    again = bb.StructureSolver(n_iter=early.n_iter_, **kw).fit(w, init=x0)
+    assert numpy.array_equal(again.structure_, early.structure_)
