@@ -52,6 +52,17 @@ BB_ABL_FLAG(kWaveTrace, true);
 #else
 BB_ABL_FLAG(kWaveTrace, false);
 #endif
+#ifdef BB_UNIT_TRACE          // diagnostic build: a time stamp at the top of EVERY unit of a wave
+BB_ABL_FLAG(kUnitTrace, true);    // (kept in LDS while the wave sweeps; tools/unit_trace.py) -- the
+#else                             // unit loop is the product's: no peeled unit, no store in it
+BB_ABL_FLAG(kUnitTrace, false);
+#endif
+constexpr int kUnitTraceSlots = 320;   // stamps kept per wave
+#ifdef BB_BUFFER_WINDOW        // A/B: the window refilled by range-checked buffer loads
+BB_ABL_FLAG(kGlobalWindow, false);
+#else
+BB_ABL_FLAG(kGlobalWindow, true);
+#endif
 #ifdef BB_ABL_NOREFILL_FIRST  // the first unit of a strip does not refill the window (wrong results:
 BB_ABL_FLAG(kNoRefillFirst, true);   // is that unit slow because its refills cannot be issued?)
 #else

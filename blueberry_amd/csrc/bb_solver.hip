@@ -49,12 +49,15 @@ struct bb_solver {
     int64_t *d_blk_ptr = nullptr, *d_blk_chunk = nullptr;    // final stage: one list per block
     int64_t *d_s1_ptr = nullptr, *d_s1_chunk = nullptr;      // stage 1: slices of long lists
     int64_t n_slices = 0, part2_off = 0;
+    int64_t *d_red_lists = nullptr;   // reduce_sliced_kernel: one padded chunk list per block
+    int red_stride = 0, red_slices = 0;   // entries per block (multiple of 16 * slices); 4 or 8 slices, 0 = old reduce
     double *d_stress_hist = nullptr, *d_stress_scalar = nullptr;
     double *d_f64_tmp = nullptr;  // (n_pad,3) staging for coordinate I/O
     void *d_mv_in = nullptr;      // (n_pad,3) right-hand sides of bb_solver_matvec_sq, kept
     int64_t rowpart_elems = 0, colpart_elems = 0;
     int n_waves = 0, n_slots = 0;
     int wpb = 4;                   // waves per workgroup of the sweep: 4, or 8 (paired, see kernel)
+    int wg_map = 0;                // block index -> run of chunks (stress_grad_kernel): 0 identity
     int defer_cap_units = 0;       // fp32: units of row sums a wave can park in LDS (0 = none)
     int64_t defer_lds_bytes = 0;   // dynamic LDS per workgroup for that, 0 = per-unit stores
     unsigned defer_attr_done = 0;  // kernel variants whose dynamic-LDS ceiling was raised
@@ -163,6 +166,21 @@ int build_indices(bb_solver *s) {
     }
     nw = bb::round_up(nw, s->wpb);
     s->n_waves = (int)nw;
+    {
+        // BB_WG_MAP: 0 identity, m > 0 multiplicative permutation (made coprime with the
+        // workgroup count), -1 one contiguous eighth of the chunks per XCD
+        const char *e = getenv("BB_WG_MAP");
+        const int64_t nwg = nw / s->wpb;
+        int m = e ? atoi(e) : 0;
+        if (m < 0 && nwg % 8 != 0) m = 0;
+        if (m > 0) {
+            auto gcd = [](int64_t a, int64_t b) { while (b) { const int64_t t = a % b; a = b; b = t; } return a; };
+            while (gcd(m, nwg) != 1) ++m;
+            m = (int)(m % nwg);
+            if (nwg * (int64_t)m >= ((int64_t)1 << 32)) m = 0;
+        }
+        s->wg_map = m;
+    }
 
     if (s->n_local >= ((int64_t)1 << 31))
         return bb::fail(BB_ERR_INVALID, "bb_solver_create: more than 2^31 units on one rank");
@@ -200,7 +218,8 @@ int build_indices(bb_solver *s) {
         // (3 * vw elements) at the end; + the 8 progress words of a paired workgroup
         const int64_t col_words = 3 * vw * bb::elem_size(s->dtype) / 4;
         s->lds_wave_floats = (int)std::max<int64_t>((int64_t)s->defer_cap_units * 12 + 4, col_words);
-        s->defer_lds_bytes = (int64_t)s->wpb * s->lds_wave_floats * 4 + 32;
+        s->defer_lds_bytes = (int64_t)s->wpb * s->lds_wave_floats * 4 + 32 +
+                             (abl::kUnitTrace ? (int64_t)s->wpb * abl::kUnitTraceSlots * 8 : 0);
     }
     // Column-partial slots.  A wave's strips but the last get private slots (it writes them
     // itself, mid-sweep: rare); the strip a wave ENDS in shares one slot with the other
@@ -284,7 +303,26 @@ int build_indices(bb_solver *s) {
     s->n_slices = (int64_t)s1_ptr.size() - 1;
     if (s1_chunk.empty()) s1_chunk.push_back(0);
     if (fin_chunk.empty()) fin_chunk.push_back(0);
-    const int64_t part_total = s->part2_off + s->n_slices * ch;
+    // reduce_sliced_kernel (the default; BB_REDUCE_OLD=1 keeps the two-stage reduce above):
+    // every block's whole list in one table of fixed stride, padded with the offset of a
+    // chunk of zeros that sits behind the stage-1 partials
+    const int64_t zero_off = s->part2_off + s->n_slices * ch;
+    const int64_t part_total = zero_off + ch;
+    std::vector<int64_t> red_lists;
+    {
+        const char *e = getenv("BB_REDUCE_OLD");
+        s->red_slices = (e && atoi(e) != 0) ? 0 : (longest <= 64 ? 4 : 8);
+        if (const char *f = getenv("BB_REDUCE_SLICES")) s->red_slices = atoi(f) == 4 ? 4 : 8;
+        if (s->red_slices > 0) {
+            const int64_t quantum = 16 * s->red_slices;
+            s->red_stride = (int)bb::round_up(std::max<int64_t>(longest, 1), quantum);
+            red_lists.assign((size_t)(nb * s->red_stride), zero_off);
+            for (int64_t b = 0; b < nb; ++b)
+                for (int64_t k = blk_ptr[b]; k < blk_ptr[b + 1]; ++k)
+                    red_lists[(size_t)(b * s->red_stride + (k - blk_ptr[b]))] = blk_chunk[k];
+        }
+    }
+    if (red_lists.empty()) red_lists.push_back(0);
 
     const int64_t es = bb::elem_size(s->dtype);
     s->hist_cap = kHistCap;
@@ -312,11 +350,13 @@ int build_indices(bb_solver *s) {
         add((char **)&s->d_part, part_total * es);
         add(&s->d_udesc, (int64_t)s->udesc.size());
         add(&s->d_wave_slots, nw);
-        add(&s->d_stresspart, nw * 9);   // nw partials (+ 8 stamps per wave, diagnostic build)
+        // nw partials (+ 8 stamps per wave, + one stamp per unit: diagnostic builds)
+        add(&s->d_stresspart, nw * (9 + (abl::kUnitTrace ? abl::kUnitTraceSlots : 0)));
         add(&s->d_blk_ptr, nb + 1);
         add(&s->d_blk_chunk, (int64_t)fin_chunk.size());
         add(&s->d_s1_ptr, (int64_t)s1_ptr.size());
         add(&s->d_s1_chunk, (int64_t)s1_chunk.size());
+        add(&s->d_red_lists, (int64_t)red_lists.size());
         add(&s->d_stress_hist, kHistCap);
         add(&s->d_stress_scalar, 1);
         add(&s->d_f64_tmp, s->L.n_pad * 3);
@@ -350,6 +390,8 @@ int build_indices(bb_solver *s) {
                                 hipMemcpyHostToDevice, st));
     BB_HIP_CHECK(hipMemcpyAsync(s->d_s1_chunk, s1_chunk.data(),
                                 s1_chunk.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    BB_HIP_CHECK(hipMemcpyAsync(s->d_red_lists, red_lists.data(),
+                                red_lists.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
     // rows of boundary tiles owned by another rank are never written: keep them 0
     BB_HIP_CHECK(hipMemsetAsync(s->d_part, 0, (size_t)part_total * es, st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_X, 0, (size_t)(s->L.n_pad * 3 * es), st));
@@ -393,7 +435,7 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
         BB_HIP_CHECK(bb::launch(kern, grid, block, (size_t)(LDS), s->stream, units, X,          \
                                 s->d_udesc, s->chunk_q, s->chunk_r, s->d_wave_slots, rowpart,   \
                                 colpart, s->d_stresspart, s->defer_cap_units,                   \
-                                s->lds_wave_floats));                                           \
+                                s->lds_wave_floats, s->wg_map));                                \
     } while (0)
 #define BB_LAUNCH2(NTV, OPV, DEF, LDS)                                                          \
     do {                                                                                        \
@@ -447,6 +489,20 @@ int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, doubl
         p.n_peers = s->world;
     }
     const unsigned segs = 3 * Lay<T, W>::VW / kRedWG;   // workgroups per block of 3*vw elements
+    if (s->red_slices > 0) {
+        // one launch: every list whole, 128 elements x 4 or 8 slices per workgroup
+        p.blk_ptr = nullptr;
+        p.blk_chunk = nullptr;
+        p.mode = mode;
+        const dim3 grid = mode == kReduceStressOnly ? dim3(1, 1) : dim3((unsigned)s->L.n_blocks, segs);
+        if (s->red_slices == 4)
+            BB_HIP_CHECK(bb::launch(reduce_sliced_kernel<T, W, 4>, grid, dim3(128 * 4), 0, s->stream,
+                                    p, (const int64_t *)s->d_red_lists, s->red_stride));
+        else
+            BB_HIP_CHECK(bb::launch(reduce_sliced_kernel<T, W, 8>, grid, dim3(128 * 8), 0, s->stream,
+                                    p, (const int64_t *)s->d_red_lists, s->red_stride));
+        return BB_OK;
+    }
     if (mode != kReduceStressOnly && s->n_slices > 0) {
         p.blk_ptr = s->d_s1_ptr;
         p.blk_chunk = s->d_s1_chunk;
@@ -1495,7 +1551,7 @@ int bb_solver_measure_stream_read(bb_solver *s, int launches, double *ms_avg) {
     return BB_OK;
 }
 
-#ifdef BB_WAVE_TRACE
+#if defined(BB_WAVE_TRACE) || defined(BB_UNIT_TRACE)
 // Diagnostic build only: `times` sweep launches back to back with nothing in between
 // (is a launch's slow first unit a cold instruction cache?).
 BB_API int bb_solver_debug_grad_repeat(bb_solver *s, int times) {
@@ -1517,6 +1573,21 @@ BB_API int bb_solver_debug_wave_trace(bb_solver *s, unsigned long long *out, int
     if (out && cap >= 8 * (int64_t)s->n_waves)
         BB_HIP_CHECK(hipMemcpy(out, s->d_stresspart + s->n_waves, (size_t)s->n_waves * 64,
                                hipMemcpyDeviceToHost));
+    return BB_OK;
+}
+// -DBB_UNIT_TRACE: kUnitTraceSlots stamps per wave of the last sweep launch: slot k = the top
+// of the wave's unit k (10-ns ticks), slot n_units = the end of its last unit, 0 = unused.
+BB_API int bb_solver_debug_unit_trace(bb_solver *s, unsigned long long *out, int64_t cap,
+                                      int64_t *n_waves, int64_t *slots) {
+    BB_REQUIRE(s != nullptr && n_waves != nullptr && slots != nullptr,
+               "bb_solver_debug_unit_trace: NULL argument");
+    BB_TRY(bb::enter_device(s->device));
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    *n_waves = s->n_waves;
+    *slots = abl::kUnitTrace ? abl::kUnitTraceSlots : 0;
+    if (out && abl::kUnitTrace && cap >= *slots * (int64_t)s->n_waves)
+        BB_HIP_CHECK(hipMemcpy(out, s->d_stresspart + (int64_t)s->n_waves * 9,
+                               (size_t)s->n_waves * abl::kUnitTraceSlots * 8, hipMemcpyDeviceToHost));
     return BB_OK;
 }
 #endif

@@ -290,13 +290,43 @@ __device__ __forceinline__ double2 stream_load(const double2 *p) {
     }
 }
 
+// Where a wave's rolling window is refilled from: the k-th wave-load (1 KiB) of the NEXT
+// unit.  WinPtr (product): plain pointers.  WinBuf (-DBB_BUFFER_WINDOW, A/B only): buffer
+// loads through a descriptor that covers exactly the wave's chunk, so that the refills of
+// a wave's last unit fall out of range and cost no traffic -- measured 1.5-2.5 us SLOWER per
+// launch at N=12,000-17,700 (the scheduler clusters the refills differently:
+// profiles/r03_window_ab.txt); the pointer form gets the same saving by pointing all lanes
+// of those last refills at one line (see window_of in the kernel).
+template <typename Vec>
+struct WinPtr {
+    const Vec *p;
+    template <bool NT>
+    __device__ __forceinline__ Vec load(int k) const { return stream_load<NT>(p + k * 64); }
+};
+template <typename Vec>
+struct WinBuf {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned off;      // byte offset of this lane's 16 bytes of wave-load 0 of the unit
+    template <bool NT>
+    __device__ __forceinline__ Vec load(int k) const {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + (unsigned)k * 1024u, 0,
+                                                              NT ? 2 : 0);   // aux bit 1 = nt
+        if constexpr (sizeof(Vec) == sizeof(float4) && std::is_same<Vec, float4>::value)
+            return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                               __uint_as_float(v.w));
+        else
+            return make_double2(__hiloint2double((int)v.y, (int)v.x),
+                                __hiloint2double((int)v.w, (int)v.z));
+    }
+};
+
 // One unit, generic (fp64) form: RPU matrix rows of LPR wave-loads each.  Load k of
 // row r of the CURRENT unit is consumed from d[r*LPR + k], which is then refilled at
 // once with the same load of the NEXT unit, so 8 KiB per wave stay in flight with a
 // single register window.  xrow.get(q): the unit's q-th row coordinate, wave-uniform.
-template <typename T, bool W, bool NT, int OP, typename XR>
+template <typename T, bool W, bool NT, int OP, typename XR, typename WIN>
 __device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[8], const XR &xrow,
-                                             const typename Traits<T>::Vec *__restrict__ next,
+                                             const WIN &next,
                                              const T (&xj)[(Lay<T, W>::LPR)][Traits<T>::VPL][3],
                                              T (&gc)[(Lay<T, W>::LPR)][Traits<T>::VPL][3],
                                              double &stress, __amdgpu_buffer_rsrc_t row_rsrc,
@@ -316,7 +346,7 @@ __device__ __forceinline__ void process_unit(typename Traits<T>::Vec (&d)[8], co
                 pair_step<T, 2, OP>(d[r * LPR + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
                 pair_step<T, 3, OP>(d[r * LPR + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
             }
-            d[r * LPR + k] = stream_load<NT>(next + (r * LPR + k) * 64);
+            d[r * LPR + k] = next.template load<NT>(r * LPR + k);
         }
         wave_sum_hi3(gx, gy, gz);
         // one 3-element store per matrix row, from the lane holding the sums
@@ -356,9 +386,9 @@ __device__ __forceinline__ double swap_sum32(double t) {
     return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
 
-template <bool NT, int OP, bool DEFER, typename XR>
+template <bool NT, int OP, bool DEFER, typename XR, typename WIN>
 __device__ __forceinline__ void process_unit_f64w(double2 (&d)[8], const XR &xrow,
-                                                  const double2 *__restrict__ next,
+                                                  const WIN &next,
                                                   const double (&xj)[4][2][3], double (&gc)[4][2][3],
                                                   const double (&sel)[6], double &stress,
                                                   __amdgpu_buffer_rsrc_t row_rsrc, unsigned row_voff,
@@ -374,7 +404,7 @@ __device__ __forceinline__ void process_unit_f64w(double2 (&d)[8], const XR &xro
         for (int k = 0; k < 4; ++k) {
             pair_step<double, 0, OP>(d[r * 4 + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
             pair_step<double, 1, OP>(d[r * 4 + k], xi, yi, zi, xj[k], gc[k], gx, gy, gz, s);
-            d[r * 4 + k] = stream_load<NT>(next + (r * 4 + k) * 64);
+            d[r * 4 + k] = next.template load<NT>(r * 4 + k);
         }
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(gx, sel[3 * r + 0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(gy, sel[3 * r + 1], acc, 0, 0, 0);
@@ -459,9 +489,9 @@ __device__ __forceinline__ void pair_step2(f32x2 delta, f32x2 xi, f32x2 yi, f32x
 }
 
 // d[] holds the unit's 8 wave-loads in row order: d[2*r + k] = row r, load k.
-template <bool NT, int OP, bool DEFER, bool REFILL = true>
+template <bool NT, int OP, bool DEFER, bool REFILL = true, typename WIN>
 __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&xrow)[12],
-                                                 const float4 *__restrict__ next, StripF32 &st,
+                                                 const WIN &next, StripF32 &st,
                                                  double &stress, __amdgpu_buffer_rsrc_t row_rsrc,
                                                  unsigned row_voff, int stage_idx) {
     extern __shared__ __attribute__((aligned(16))) float row_lds[];
@@ -480,12 +510,12 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&x
         f32x2 rx, ry, rz, qx, qy, qz;  // row-side sums of load 0 / load 1
         pair_step2<0, 0, true, OP>(f32x2{d[2 * r].x, d[2 * r].y}, xi, yi, zi, st, rx, ry, rz, s2);
         pair_step2<0, 1, false, OP>(f32x2{d[2 * r].z, d[2 * r].w}, xi, yi, zi, st, rx, ry, rz, s2);
-        if constexpr (REFILL) d[2 * r] = stream_load<NT>(next + (2 * r) * 64);
+        if constexpr (REFILL) d[2 * r] = next.template load<NT>(2 * r);
         // (no sched_barrier here: letting the scheduler mix the rows of a unit measured
         // 1 % faster at N=50k and 6 % faster at 1/8 size; it stays within 125 VGPRs)
         pair_step2<1, 0, true, OP>(f32x2{d[2 * r + 1].x, d[2 * r + 1].y}, xi, yi, zi, st, qx, qy, qz, s2);
         pair_step2<1, 1, false, OP>(f32x2{d[2 * r + 1].z, d[2 * r + 1].w}, xi, yi, zi, st, qx, qy, qz, s2);
-        if constexpr (REFILL) d[2 * r + 1] = stream_load<NT>(next + (2 * r + 1) * 64);
+        if constexpr (REFILL) d[2 * r + 1] = next.template load<NT>(2 * r + 1);
         rx += qx; ry += qy; rz += qz;
         float gx = rx.x + rx.y, gy = ry.x + ry.y, gz = rz.x + rz.y;
         if constexpr (!abl::kNoDpp) wave_sum_hi3(gx, gy, gz);
@@ -596,7 +626,7 @@ __device__ __forceinline__ void store_strip(const T (&gc)[(Lay<T, W>::LPR)][Trai
 // constant-rate clock, into a region of its own behind the per-wave stress partials
 // (nothing reads it but bb_solver_debug_wave_trace).  Folds away in the product build.
 __device__ __forceinline__ void wave_stamp(double *stresspart, int n_waves, int w, int k) {
-    if constexpr (abl::kWaveTrace) {
+    if constexpr (abl::kWaveTrace || abl::kUnitTrace) {
         if ((threadIdx.x & 63) == 0) {
             unsigned long long *t = reinterpret_cast<unsigned long long *>(stresspart + n_waves);
             unsigned long long v = (unsigned long long)wall_clock64();
@@ -652,13 +682,22 @@ template <typename T, bool W, bool NT, int OP, bool DEFER, int WPB>
 __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_kernel(
     const T *__restrict__ units, const T *__restrict__ X, const int2 *__restrict__ udesc,
     int chunk_q, int chunk_r, const int2 *__restrict__ wave_slots, T *__restrict__ rowpart,
-    T *__restrict__ colpart, double *__restrict__ stresspart, int cap_units, int lds_wave_floats) {
+    T *__restrict__ colpart, double *__restrict__ stresspart, int cap_units, int lds_wave_floats,
+    int wg_map) {
     using Vec = typename Traits<T>::Vec;
     constexpr int VPL = Traits<T>::VPL;
     constexpr int VW = Lay<T, W>::VW;
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave in workgroup
-    const int w = blockIdx.x * WPB + wib;
+    // Which run of WPB chunks this workgroup sweeps: a bijection of the block index (the
+    // host checks it is one).  0: the identity.  m > 0: (b * m) mod n.  -1: block b -- on XCD
+    // b mod 8 under round-robin placement -- takes chunk (b mod 8) * n / 8 + b / 8, i.e.
+    // every XCD sweeps one contiguous eighth of the units.  Speed only: every chunk is swept
+    // exactly once whatever the placement.
+    const int wg = wg_map == 0 ? (int)blockIdx.x
+                 : wg_map > 0 ? (int)(((unsigned)blockIdx.x * (unsigned)wg_map) % gridDim.x)
+                              : (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+    const int w = wg * WPB + wib;
     // wave w owns units [w*q + min(w, r), +q (+1 if w < r)): arithmetic, not a table --
     // one dependent memory round trip less before the wave's first matrix load
     const int ua = w * chunk_q + (w < chunk_r ? w : chunk_r);
@@ -667,6 +706,12 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
     wave_stamp(stresspart, n_waves_all, w, 0);      // (diagnostic build only)
     wave_stamp(stresspart, n_waves_all, w, 4);
     double stress = 0.0;
+    // the shared column slots of this workgroup's waves (epilogue), read NOW: behind the
+    // fences further down the compiler no longer takes them through the scalar cache, and a
+    // vector load there waits -- vmcnt is in order -- for every store the wave has in flight
+    int ws_shared[WPB];
+#pragma unroll
+    for (int k = 0; k < WPB; ++k) ws_shared[k] = wave_slots[(int64_t)wg * WPB + k].y;
     // DEFER: this wave's parking space, cap_units * 12 floats + 4 dummy words
     extern __shared__ __attribute__((aligned(16))) float row_lds[];
     // this wave's LDS region: row-sum parking while it sweeps, its last column partial at
@@ -736,10 +781,28 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
             return x;
         };
         XRow xr = xrow_load(dc.x);
+        using Win = typename std::conditional<abl::kGlobalWindow, WinPtr<Vec>, WinBuf<Vec>>::type;
+        // the wave's chunk as a buffer: (ub - ua) units of 8 KiB (< 4 GiB: the host checks)
+        const __amdgpu_buffer_rsrc_t win_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T *>(units) + (int64_t)ua * (8192 / (int)sizeof(T)), 0,
+            (int)((unsigned)(ub - ua) * 8192u), 0x00020000);
+        auto window_of = [&](int u_next) __attribute__((always_inline)) {
+            if constexpr (abl::kGlobalWindow) {
+                // The refills of the wave's LAST unit are never consumed.  They stay in the
+                // loop (a branch around them would cost every unit its exact wait counts),
+                // but all lanes ask for the same 16 bytes of the chunk's last unit: 8 lines
+                // instead of 8 KiB per wave and launch (1.3-2.7 % of the bytes of a 1/8 share
+                // of N=50k), back at once, so the epilogue gets the window's registers early.
+                const bool real = u_next < ub;
+                return Win{unit_ptr<T>(units, real ? u_next : ub - 1, real ? lane : 0)};
+            } else {
+                return Win{win_rsrc, (unsigned)(u_next - ua) * 8192u + (unsigned)lane * 16u};
+            }
+        };
         {
-            const Vec *first = unit_ptr<T>(units, ua, lane);
+            const Win first = window_of(ua);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) d[r] = stream_load<NT>(first + r * 64);
+            for (int r = 0; r < 8; ++r) d[r] = first.template load<NT>(r);
         }
         if constexpr (abl::kWaveTrace) {     // diagnostic build: when does the first data land?
             asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
@@ -754,7 +817,22 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
             0x00020000);
 
         // `first`: the peeled first unit of a strip (a timing experiment may treat it apart)
+        // -DBB_UNIT_TRACE: the time at the top of unit k goes to LDS slot k of the wave one
+        // unit later (by then it has certainly arrived: no wait of its own), branch-free
+        unsigned long long t_prev = 0;
+        unsigned long long *ut_lds = reinterpret_cast<unsigned long long *>(
+            row_lds + WPB * lds_wave_floats + 8 + 2 * abl::kUnitTraceSlots * wib);
+        auto unit_stamp = [&](int k) __attribute__((always_inline)) {
+            if constexpr (abl::kUnitTrace) {
+                const unsigned long long t_now = (unsigned long long)wall_clock64();
+                const int sl = (lane == 0 && k >= 1 && k <= abl::kUnitTraceSlots - 2)
+                                   ? k - 1 : abl::kUnitTraceSlots - 1;   // last slot: dummy
+                ut_lds[sl] = t_prev;
+                t_prev = t_now;
+            }
+        };
         auto unit_step = [&](int u, auto first) __attribute__((always_inline)) {
+            unit_stamp(u - ua);
             if constexpr (WPB == 8) {
                 // pace keeping (see the kernel's comment): the partner's count was read
                 // one unit ago, so nothing here waits on LDS
@@ -767,7 +845,7 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
                 partner_done = __hip_atomic_load(progress + (wib ^ 4), __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            // the wave's last unit "prefetches" itself: harmless, stays in bounds
+            // (the descriptors of the units behind the wave's last one are never used)
             const int un = u + 1 < ub ? u + 1 : u;
             const XRow xrn = xrow_load(dn.x);
             const int2 dnn = udesc[un + 1 < ub ? un + 1 : un];
@@ -802,13 +880,13 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
 #pragma unroll
                 for (int q = 0; q < 12; ++q) xs12[q] = xr.get(q);
                 process_unit_f32<NT, OP, DEFER, !(decltype(first)::value && abl::kNoRefillFirst)>(
-                    d, xs12, unit_ptr<T>(units, un, lane), st, stress, row_rsrc, row_voff, stage_slot);
+                    d, xs12, window_of(u + 1), st, stress, row_rsrc, row_voff, stage_slot);
             }
             else if constexpr (W && !abl::kF64Generic)
-                process_unit_f64w<NT, OP, DEFER>(d, xr, unit_ptr<T>(units, un, lane), st.xj, st.gc,
+                process_unit_f64w<NT, OP, DEFER>(d, xr, window_of(u + 1), st.xj, st.gc,
                                                  sel, stress, row_rsrc, row_voff, stage_slot);
             else
-                process_unit<T, W, NT, OP>(d, xr, unit_ptr<T>(units, un, lane), st.xj, st.gc, stress,
+                process_unit<T, W, NT, OP>(d, xr, window_of(u + 1), st.xj, st.gc, stress,
                                        row_rsrc, row_voff);
             xr = xrn;
             dc = dn;
@@ -875,6 +953,17 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
             __builtin_amdgcn_s_setprio(0);
         }
         wave_stamp(stresspart, n_waves_all, w, 2);                    // last unit consumed
+        if constexpr (abl::kUnitTrace) {
+            // slot k = top of unit k, slot n = end of the last unit; out to HBM behind the stamps
+            unit_stamp(ub - ua);
+            unit_stamp(ub - ua + 1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            unsigned long long *out = reinterpret_cast<unsigned long long *>(stresspart + n_waves_all * 9) +
+                                      (long long)w * abl::kUnitTraceSlots;
+            for (int q = lane; q < abl::kUnitTraceSlots - 1; q += 64)
+                out[q] = q <= ub - ua && q <= abl::kUnitTraceSlots - 3 ? ut_lds[q] : 0ull;
+        }
         if constexpr (DEFER) {
             // the chunk's row sums, 48 bytes per unit in either precision (12 floats or
             // 6 doubles), in one contiguous burst.
@@ -908,16 +997,20 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
     // of the bytes for the sweep to write and for the reduce to read back.  wave_slots[].y
     // names the shared slot; waves of one workgroup that end in the same strip carry the
     // same number (the host deals them, and with BB_WG_COLSUM=0 deals every wave its own).
-    __syncthreads();
+    // The barrier orders LDS only: __syncthreads() is also a release of the wave's global
+    // stores, and waiting here for the acknowledgement of the row-sum burst (s_waitcnt vmcnt
+    // in front of s_barrier) kept every wave 1-2 us at the end of every launch.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     {
         constexpr int CH = 3 * VW, NTH = 64 * WPB;
-        const int2 *ws = wave_slots + (int64_t)blockIdx.x * WPB;
         int k = 0;
         while (k < WPB) {
-            const int sl = ws[k].y;            // wave-uniform (scalar loads)
+            const int sl = ws_shared[k];       // wave-uniform (scalar registers)
             if (sl < 0) { ++k; continue; }
             int k2 = k + 1;
-            while (k2 < WPB && ws[k2].y == sl) ++k2;
+            while (k2 < WPB && ws_shared[k2] == sl) ++k2;
             T *dst = colpart + (int64_t)sl * CH;
 #pragma unroll
             for (int j = 0; j < (CH + NTH - 1) / NTH; ++j) {
@@ -1113,6 +1206,122 @@ __global__ __launch_bounds__(kRedWG) void reduce_kernel(ReduceParams<T> p) {
     }
 }
 
+
+// ---- the reduce in ONE launch of one memory round trip (round 3) ------------------
+// reduce_kernel above walks a block's list with one thread per element: a list of L chunks
+// is ceil(L / 16) dependent round trips behind three more (kernel arguments -> blk_ptr ->
+// blk_chunk), and lists beyond 128 chunks take a second launch.  The kernel trace has that
+// chain at 6.2-7.4 us per iteration from N=8,000 to 17,700 and 11-13 us at N=24,926 -- 6 % of
+// a 1/8 share of N=50k.  Here a workgroup is 128 elements x S slices of the list (S = 4 or
+// 8): every thread has its whole slice -- 16 chunks per trip -- in flight at once, the
+// slices meet in LDS and are added in slice order (fixed: bitwise reproducible), and the
+// lists come as ONE table of fixed stride (`list_stride` entries per block, padded with the
+// offset of a chunk of zeros), so the table's address does not wait for a blk_ptr and no
+// load is predicated.  A wave is one slice of 64 elements: its table entries are
+// wave-uniform and travel through the scalar cache.
+template <typename T, bool W, int S>
+__global__ __launch_bounds__(128 * S) void reduce_sliced_kernel(ReduceParams<T> p,
+                                                                const int64_t *__restrict__ lists,
+                                                                int list_stride) {
+    constexpr int CH = 3 * Lay<T, W>::VW;
+    static_assert(CH % kRedWG == 0, "3*vw is a multiple of 128");
+    const int tid = threadIdx.x;
+    const int el = tid & (kRedWG - 1);
+    const int sl = __builtin_amdgcn_readfirstlane(tid >> 7);      // slice: uniform per wave
+    const int b = blockIdx.x;
+    const int e = (int)blockIdx.y * kRedWG + el;                  // element of the block, < CH
+    __shared__ __attribute__((aligned(16))) T meet[S][kRedWG];
+    const bool peer_live =
+        p.mode != kReducePeer ||
+        __hip_atomic_load(&p.peer_state->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    if (p.mode != kReduceStressOnly) {
+        const int lps = list_stride / S;                          // a multiple of 16
+        const int64_t *list = lists + (int64_t)b * list_stride + (int64_t)sl * lps;
+        const int64_t o = (int64_t)b * CH + e;
+        T xo = T(0), vo = T(0);
+        if (p.mode == kReduceApply && sl == 0) { xo = p.X[o]; vo = p.V[o]; }   // early: independent
+        T acc = T(0);
+        for (int k = 0; k < lps; k += 16) {
+            T v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = p.part[list[k + q] + e];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc += v[q];
+        }
+        meet[sl][el] = acc;
+        __syncthreads();
+        if (sl == 0) {
+            T tot = meet[0][el];
+#pragma unroll
+            for (int q = 1; q < S; ++q) tot += meet[q][el];
+            const T g = p.scale * tot;
+            if (p.mode == kReduceApply) {
+                // SPEC 2.4: V <- mu V - lr g ; X <- X + V   (mu = 0: X -= lr g)
+                const T v = p.mu * vo - p.lr * g;
+                p.V[o] = v;
+                p.X[o] = xo + v;
+            } else if (p.mode == kReducePeer) {
+                meet[0][el] = g;
+            } else {
+                p.exch[o] = g;
+            }
+        }
+        if (p.mode == kReducePeer && peer_live) {
+            typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+            constexpr int NV = kRedWG * (int)sizeof(T) / 16;
+            __syncthreads();
+            if (tid < NV) {
+                const vec_t val = ((const vec_t *)meet[0])[tid];
+                for (int q = 0; q < p.n_peers; ++q)
+                    ((vec_t *)(p.peer->dst[q] + (int64_t)b * CH + (int64_t)blockIdx.y * kRedWG))[tid] = val;
+            }
+        }
+    }
+    if (b == 0 && blockIdx.y == 0) {
+        // the stress: per-wave partials of the sweep, fixed tree
+        __shared__ double sh[128 * S];
+        double s = 0.0;
+        for (int i = tid; i < p.n_waves; i += 128 * S) s += p.stresspart[i];
+        sh[tid] = s;
+        __syncthreads();
+        for (int off = 64 * S; off > 0; off >>= 1) {
+            if (tid < off) sh[tid] += sh[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double Sx = sh[0];
+            if (p.mode == kReduceExchange) {
+                const T hi = (T)Sx;
+                p.exch[3 * p.n_pad] = hi;
+                p.exch[3 * p.n_pad + 1] = (T)(Sx - (double)hi);
+            } else if (p.mode == kReducePeer) {
+                const T hi = (T)Sx, lo = (T)(Sx - (double)hi);
+                for (int q = 0; q < (peer_live ? p.n_peers : 0); ++q) {
+                    p.peer->dst[q][3 * p.n_pad] = hi;
+                    p.peer->dst[q][3 * p.n_pad + 1] = lo;
+                }
+            } else {
+                *p.stress_out = Sx;
+            }
+        }
+    }
+    if (p.mode == kReducePeer && peer_live) {
+        // as in reduce_kernel: every workgroup makes its stores visible system-wide and
+        // checks in; the last one raises this rank's flag on every peer (release)
+        __shared__ int last;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope
+        __syncthreads();
+        if (tid == 0) last = atomicAdd(p.peer_counter, 1u) == gridDim.x * gridDim.y - 1;
+        __syncthreads();
+        if (last) {
+            if (tid == 0) atomicExch(p.peer_counter, 0u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (tid < p.n_peers)
+                __hip_atomic_store(p.peer->flag[tid], p.seq, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 
 // Peer exchange, receiving side -- one launch.  Wave 0 of workgroup 0 waits until every
 // source rank's flag has reached `seq` and publishes the outcome (state->verdict = seq);

@@ -10,7 +10,7 @@ import sys
 
 
 def short(name):
-    for key in ("stress_grad_kernel", "reduce_kernel", "row_owner_kernel", "apply_kernel",
+    for key in ("stress_grad_kernel", "reduce_sliced_kernel", "reduce_kernel", "row_owner_kernel", "apply_kernel",
                 "peer_receive_kernel", "iterate_kernel", "sweep_reduce_kernel"):
         if key in name:
             return key
@@ -29,7 +29,7 @@ def main():
                          int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"])))
     rows.sort()
     # segments: maximal runs of loop kernels; a marker kernel (copyBuffer etc.) ends one
-    loop = ("stress_grad_kernel", "reduce_kernel", "row_owner_kernel", "apply_kernel",
+    loop = ("stress_grad_kernel", "reduce_sliced_kernel", "reduce_kernel", "row_owner_kernel", "apply_kernel",
             "peer_receive_kernel", "iterate_kernel", "sweep_reduce_kernel")
     seg, segs = [], []
     for r in rows:
