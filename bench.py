@@ -181,12 +181,15 @@ def cpu_baseline(n, iters):
     return out
 
 
+PMC_TABLE = "profiles/pmc_latest.json"
+
+
 def pmc_traffic(n_bins, dtype, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
     passes on this configuration (profiles/pmc_latest.json: one entry per problem
     size, written by tools/tools_pmc.sh), or None.  It is replayed from the profile,
     not measured in this run: counters need their own rocprofv3 passes."""
-    p = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    p = os.path.join(ROOT, PMC_TABLE)
     try:
         with open(p) as fh:
             d = json.load(fh)
@@ -342,9 +345,14 @@ def main():
         eng.sync()                           # (tools/state_probe.py), clocks do on the load
     steps(a.warmup)
     fence()
-    # HIP events on every 8th step of the timed region: three records cost ~10 us of
-    # stream time, too much to put on every step once a step is ~0.1 ms (8 GPUs)
-    eng.set_timing((a.event_stride if a.steps >= 16 else 1) if a.event_stride > 0 else 0)
+    # HIP events on a sample of the steps of the timed region: three records cost ~10 us of
+    # stream time, too much to put on every step once a step is ~0.1 ms (8 GPUs).  At least
+    # 8 launches are sampled whatever --steps is (4 on several ranks, where a step is short),
+    # so that the sampled launches are the average ones: with --steps 20 and a fixed stride
+    # of 8 round 2 timed 3 launches, and kernel + reduce came out above the device step.
+    want = 8 if world == 1 else 4
+    stride = max(1, min(a.event_stride, a.steps // want)) if a.event_stride > 0 else 0
+    eng.set_timing(stride)
     t0 = time.perf_counter()
     steps(a.steps)
     fence()
@@ -433,6 +441,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(n, a.dtype, world),
+                         # counters need rocprofv3 passes of their own: replayed, not measured here
+                         "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                            "this configuration, replayed)" % PMC_TABLE)
+                         if pmc_traffic(n, a.dtype, world) is not None else None,
                          "kernel": kernel,
                          "kernel_ms": tim["grad_ms"], "reduce_update_ms": tim["reduce_ms"],
                          # start-to-start of consecutive steps on the device: what is

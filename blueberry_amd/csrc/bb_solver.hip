@@ -119,10 +119,14 @@ int dev_alloc(T **p, int64_t count) {
 // per rank (N=24,926) up, 4 and 8 tie at 77k units (1/8 of the N=50k matrix, where
 // 4 means half as many column partials for the reduce), 6 is always worse (a
 // workgroup count that is not a multiple of the CU count), 16 is 2 % slower.
+// Round 3, with the one-launch reduce (whose time no longer grows with the number of
+// column slots) and by the kernel trace (tools/wpc_timeline.sh, profiles/r03_wpc_ab.txt): 8
+// per CU takes 110.3-111.9 us per iteration at N=17,700 against 116.3-116.5 with 4, and ties
+// at N=12,000 and 14,500: the switch is at 65k units (N ~ 16,200 on one rank).
 // BB_WAVES_PER_CU overrides.
 int waves_per_cu(int64_t n_local) {
     const char *e = getenv("BB_WAVES_PER_CU");
-    int v = e ? atoi(e) : (n_local >= 100000 ? 8 : 4);
+    int v = e ? atoi(e) : (n_local >= 65000 ? 8 : 4);
     if (v < 1) v = 1;
     if (v > 32) v = 32;
     return v;

@@ -457,8 +457,13 @@ class FithicContactMap(object):
         self.resolution = resolution
         mids = (self.map[:, :2].astype(numpy.int64) + resolution) // resolution * resolution \
             - resolution // 2
-        key, inv = numpy.unique(mids, axis=0, return_inverse=True)
-        inv = inv.ravel()
+        key, first, inv = numpy.unique(mids, axis=0, return_index=True, return_inverse=True)
+        # one row per (mid1, mid2) in the order of FIRST occurrence: the reference collects
+        # them in a dict (`datatypes.pyx:330-336`), whose order that is
+        order = numpy.argsort(first, kind="stable")
+        rank = numpy.empty_like(order)
+        rank[order] = numpy.arange(order.shape[0])
+        key, inv = key[order], rank[inv.ravel()]
         count = numpy.zeros(key.shape[0])
         numpy.add.at(count, inv, self.map[:, 2])
         p = numpy.ones(key.shape[0])

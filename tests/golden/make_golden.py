@@ -22,6 +22,9 @@ Functions captured (reference file:line):
   ContactMap.normalize    blueberry/datatypes.pyx:143-171
   ContactMap.filter       blueberry/datatypes.pyx:122-141
   FithicContactMap        blueberry/datatypes.pyx:274-388 (__init__, contacts, to_matrix)
+  FithicContactMap.decimate  blueberry/datatypes.pyx:317-339 (midpoints that are multiples of
+                          the target resolution: there Python 2's integer division, which the
+                          line was written for, and Python 3's true division give the same bins)
 """
 import os
 import shutil
@@ -211,6 +214,44 @@ def make_fithic(dt, tmp):
     print("fithic map cases written", fm.map.shape, out["fh_contacts"].shape)
 
 
+def make_fithic_decimate(dt, tmp):
+    """The real FithicContactMap.decimate (datatypes.pyx:317-339).  Its rounding line
+    `(mid.astype('int') + r) / r * r - r/2` means floor division under Python 2 and true
+    division here; for midpoints that are exact multiples of r both give mid + r/2, so on
+    such a map what this captures IS the reference's aggregation: counts summed, p-values
+    multiplied in file order, q-values minimised, one row per (mid1, mid2) in the order of
+    first occurrence (dict insertion order)."""
+    import gzip
+    rng = numpy.random.default_rng(8)
+    data_dir = os.path.join(tmp, "fithic_dec")
+    os.makedirs(data_dir)
+    dt.DATA_DIR = os.path.join(data_dir, "{0}.chr{1}.res{2}.significances.txt.gz")
+    r, n_keys, n_rows = 5000, 40, 130
+    k1 = rng.integers(0, 60, n_keys)
+    k2 = k1 + rng.integers(1, 30, n_keys)
+    pick = numpy.concatenate([numpy.arange(n_keys), rng.integers(0, n_keys, n_rows - n_keys)])
+    pick = rng.permutation(pick)
+    mid1, mid2 = k1[pick] * r, k2[pick] * r                  # exact multiples of r
+    cc = rng.integers(1, 50, n_rows)
+    pv = rng.random(n_rows) ** 2
+    qv = numpy.minimum(1.0, pv * 3)
+    path = dt.DATA_DIR.format("cellG", 9, 1000)
+    with gzip.open(path, "wt") as fh:
+        fh.write("chr1\tfragmentMid1\tchr2\tfragmentMid2\tcontactCount\tp-value\tq-value\n")
+        for k in range(n_rows):
+            fh.write("9\t%d\t9\t%d\t%d\t%.10e\t%.10e\n" % (mid1[k], mid2[k], cc[k], pv[k], qv[k]))
+    fm = dt.FithicContactMap("cellG", 9, 1000)
+    out = {"dec_in_map": fm.map.copy(), "dec_in_resolution": numpy.int64(1000),
+           "dec_resolution": numpy.int64(r)}
+    assert fm.decimate(r) is None
+    out["dec_map"], out["dec_regions"] = fm.map.copy(), fm.regions.copy()
+    out["dec_resolution_attr"] = numpy.int64(fm.resolution)
+    n_distinct = numpy.unique(numpy.stack([mid1, mid2], axis=1), axis=0).shape[0]
+    assert out["dec_map"].shape[0] == n_distinct < n_rows == out["dec_in_map"].shape[0]
+    numpy.savez_compressed(os.path.join(OUT, "fithic_decimate.npz"), **out)
+    print("fithic decimate case written", out["dec_in_map"].shape, "->", out["dec_map"].shape)
+
+
 def main():
     tmp = tempfile.mkdtemp(prefix="bbref_")
     try:
@@ -219,6 +260,7 @@ def main():
         make_bh_downsample(bb)
         make_contactmap(dt, tmp)
         make_fithic(dt, tmp)
+        make_fithic_decimate(dt, tmp)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
         shutil.rmtree(os.path.expanduser("~/.pyxbld"), ignore_errors=True)

@@ -269,6 +269,21 @@ def test_fithic_decimate_py2_semantics():
     assert numpy.allclose(fm.map, want) and numpy.array_equal(fm.regions, [2500.0, 7500.0, 12500.0])
 
 
+def test_fithic_decimate_equals_the_reference_class():
+    """`FithicContactMap.decimate` against the REAL class (`datatypes.pyx:317-339`), captured
+    by tests/golden/make_golden.py on a map whose midpoints are exact multiples of the target
+    resolution (there the line's Python 2 integer division and Python 3's true division
+    agree): 130 rows over 38 bin pairs -- counts summed, p-values multiplied in file order,
+    q-values minimised, rows in the order of first occurrence.  Bit for bit."""
+    from tests import _oracle
+    z = _oracle.golden("fithic_decimate")
+    fm = bb.FithicContactMap.from_array(z["dec_in_map"], int(z["dec_in_resolution"]))
+    assert fm.decimate(int(z["dec_resolution"])) is None
+    assert fm.resolution == int(z["dec_resolution_attr"])
+    assert numpy.array_equal(fm.map, z["dec_map"])
+    assert numpy.array_equal(fm.regions, z["dec_regions"])
+
+
 def test_early_stop_with_tolerance():
     from tests._engines import OracleEngine
     from tests import _oracle

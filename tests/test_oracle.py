@@ -224,3 +224,104 @@ def test_solver_oracle_equals_sklearn_smacof_on_a_complete_map(oracle):
         assert abs(stress / hist[it + 1] - 1) < 1e-9, (it, stress, hist[it + 1])
         mine = iterates[it + 1] - iterates[it + 1].mean(axis=0)
         assert numpy.abs(Xs - mine).max() < 1e-9 * numpy.abs(mine).max(), it
+
+
+# ---- an independent restatement of SPEC 2.1-2.4 ----------
+# The C oracle's solver has no reference to be pinned to, and its weighted branch
+# (incomplete maps, counts -> delta, the eps^2 floor, momentum) was until round 3 checked
+# against the oracle itself, finite differences and -- complete maps only -- scikit-learn.
+# This is SPEC 2.1-2.4 written a second time, from the formulas and not from the C: dense
+# numpy over all ordered pairs, no loops over pairs, a different summation order.
+def _spec_wish(counts, alpha=3.0):                       # SPEC 2.1
+    c = numpy.asarray(counts, dtype=numpy.float64)
+    ok = numpy.isfinite(c) & (c > 0)
+    w = numpy.where(ok, numpy.power(numpy.where(ok, c, 1.0), -1.0 / alpha), 0.0)
+    numpy.fill_diagonal(w, 0.0)
+    return w
+
+
+def _spec_stress_grad(wish, X, eps2):                    # SPEC 2.2, 2.3
+    sym = numpy.triu(wish, 1)
+    sym = sym + sym.T                                    # only [i][j], i < j, counts
+    diff = X[:, None, :] - X[None, :, :]
+    d = numpy.sqrt((diff ** 2).sum(axis=2) + eps2)
+    on = sym > 0
+    res = numpy.where(on, d - sym, 0.0)
+    stress = 0.5 * (res ** 2).sum()                      # every pair appears twice
+    grad = (2.0 * (res / d)[:, :, None] * diff).sum(axis=1)
+    return stress, grad
+
+
+def _spec_solve(wish, X0, iters, lr, mu, eps2):          # SPEC 2.4
+    X, V, hist = X0.copy(), numpy.zeros_like(X0), []
+    for _ in range(iters):
+        s, g = _spec_stress_grad(wish, X, eps2)
+        hist.append(s)
+        V = mu * V - lr * g
+        X = X + V
+    return X, numpy.array(hist)
+
+
+def _awkward_counts(n, seed):
+    """A count matrix with everything SPEC 2.1 has a clause for: zeros (about half the
+    pairs), whole rows without any contact, inf, NaN and negative entries.  Symmetric, as
+    every ContactMap matrix is by construction (datatypes.pyx:115-116): the device packs
+    [i][j], i < j, the C oracle walks `for i: for j < i` like blueberry.pyx:86-87."""
+    rng = numpy.random.default_rng(seed)
+    c = rng.gamma(0.7, 40.0, (n, n))
+    c[rng.random((n, n)) < 0.5] = 0.0
+    c = numpy.triu(c, 1)
+    c = c + c.T
+    c[[3, n // 2]] = 0.0
+    c[:, [3, n // 2]] = 0.0                              # two bins nobody touches
+    c[1, 7] = c[7, 1] = numpy.inf
+    c[2, 9] = c[9, 2] = numpy.nan
+    c[4, 11] = c[11, 4] = -5.0
+    return c
+
+
+@pytest.mark.parametrize("f64", [True, False])
+def test_solver_oracle_equals_the_numpy_restatement_on_incomplete_maps(oracle, f64):
+    n, k = 40, 12
+    eps2 = 1e-300 if f64 else 1e-30
+    counts = _awkward_counts(n, 5)
+    w_c = oracle.counts_to_wish(counts)
+    w_np = _spec_wish(counts)
+    # libm's pow and numpy's may differ in the last bit; "no constraint" must agree exactly
+    assert numpy.array_equal(w_c > 0, w_np > 0) and numpy.array_equal(w_c, w_c.T)
+    assert numpy.abs(w_c - w_np).max() <= 4e-16 * w_np.max()
+    w_np = w_c.copy()                                    # same bits into both solvers
+    assert (numpy.triu(w_np, 1) > 0).sum() < 0.6 * n * (n - 1) / 2      # really incomplete
+    X = numpy.random.default_rng(6).standard_normal((n, 3)) * 3.0
+    X[20] = X[21]                                        # coincident points: d = eps, force 0
+    s_c, g_c = oracle.stress_grad(w_c, X, f64=f64)
+    s_np, g_np = _spec_stress_grad(w_np, X, eps2)
+    assert abs(s_c / s_np - 1) < 1e-13
+    assert numpy.abs(g_c - g_np).max() < 1e-13 * numpy.abs(g_np).max()
+    assert numpy.all(g_c[[3, n // 2]] == 0.0) and numpy.all(numpy.isfinite(g_c))
+    lr = 1.0 / (2 * n)
+    for mu in (0.0, 0.5):
+        if mu == 0.0:
+            X_c, h_c = oracle.solve(w_c, X, k, lr, f64=f64)
+        else:
+            X_c, h_c = oracle.solve_momentum(w_c, X, k, lr, mu, f64=f64)
+        X_np, h_np = _spec_solve(w_np, X, k, lr, mu, eps2)
+        assert numpy.abs(h_c / h_np - 1).max() < 1e-12, mu
+        assert numpy.abs(X_c - X_np).max() < 1e-12 * numpy.abs(X_np).max(), mu
+        assert numpy.array_equal(X_c[[3, n // 2]], X[[3, n // 2]])      # unconstrained bins stay
+
+
+def test_numpy_restatement_on_a_wish_matrix_with_bad_entries(oracle):
+    """kind='wish': anything that is not a finite positive number is "no constraint"."""
+    n = 30
+    xs = _oracle.random_walk(n, 2)
+    w = _oracle.wish_from_coords(xs)
+    w[0, 5] = w[5, 0] = 0.0
+    w[1, 6] = w[6, 1] = -1.0
+    w[2, 8] = w[8, 2] = numpy.nan
+    X = _oracle.noisy_init(xs, 3)
+    s_c, g_c = oracle.stress_grad(w, X)
+    w_np = numpy.where(numpy.isfinite(w) & (w > 0), w, 0.0)
+    s_np, g_np = _spec_stress_grad(w_np, X, 1e-300)
+    assert abs(s_c / s_np - 1) < 1e-13
+    assert numpy.abs(g_c - g_np).max() < 1e-13 * numpy.abs(g_np).max()
