@@ -21,7 +21,7 @@ missing -- there is no CPU fallback.
 from .utils import (HIGH_FITHIC_CUTOFF, LOW_FITHIC_CUTOFF, Q_LOWER_BOUND,  # noqa: F401
                     Q_UPPER_BOUND)
 from .band import count_band_regions  # noqa: F401
-from .datatypes import ContactMap, FithicContactMap  # noqa: F401
+from .datatypes import ContactMap, EigenNoConvergence, FithicContactMap  # noqa: F401
 from .solver import HipEngine, StructureSolver  # noqa: F401
 from .stats import benjamini_hochberg, downsample  # noqa: F401
 

@@ -67,6 +67,10 @@ SIGNATURES = {
     "bb_solver_peer_set_timeout": (c_int, [c_void_p, c_i64]),
     "bb_solver_comm_world": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "bb_solver_comm_abort": (c_int, [c_void_p]),
+    "bb_comm_cached": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int)]),
+    "bb_solver_comm_attach": (c_int, [c_void_p]),
+    "bb_solver_comm_detach": (c_int, [c_void_p]),
+    "bb_comm_cache_clear": (c_int, []),
     "bb_solver_sync_timeout": (c_int, [c_void_p, c_i64]),
     "bb_solver_exchange_size": (c_int, [c_void_p, p_i64]),
     "bb_solver_get_exchange_buffer": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),

@@ -9,6 +9,8 @@
 // issue-bound, not HBM-bound; it is the structural template for the pair
 // tiling (j-chunk staged in LDS N-body style, one thread per i, wavefront
 // shuffle reduction, one integer atomic per workgroup).
+#include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
@@ -68,6 +70,60 @@ __global__ __launch_bounds__(kIB) void band_count_kernel(const double *__restric
     }
 }
 
+// Fast path for SORTED input.  `regions` is sorted whenever it comes from a ContactMap or a
+// FithicContactMap (numpy.union1d, reference datatypes.pyx:119-120, 315), and then row i's
+// hits are one contiguous run of j: d_j = r[i] - r[j] does not increase with j (fp64
+// subtraction is monotone), so  #{j < i : lo <= d_j <= hi} = (#j with d_j >= lo) -
+// (#j with d_j > hi), two binary searches with the SAME fp64 subtract and compares as the
+// double loop -- exact, O(N log N) instead of O(N^2): N=309,568 in microseconds where the
+// brute-force kernel takes 5.8 ms.  The kernel checks what it relies on: out[1] becomes
+// non-zero if any r[k] > r[k+1] or a value is not finite (NaN compares false), and the
+// caller then runs band_count_kernel, which needs no order.
+__global__ __launch_bounds__(kIB) void band_count_sorted_kernel(
+    const double *__restrict__ r, int64_t n, double lo, double hi, int64_t i_begin, int64_t i_end,
+    unsigned long long *__restrict__ out) {
+    const int tid = threadIdx.x;
+    const int64_t gid = (int64_t)blockIdx.x * kIB + tid, gsz = (int64_t)gridDim.x * kIB;
+    bool bad = false;
+    for (int64_t k = gid; k + 1 < n; k += gsz) bad |= !(r[k] <= r[k + 1]);
+    if (gid == 0) bad |= !(r[0] > -1.7976931348623157e308 && r[n - 1] < 1.7976931348623157e308);
+    const int64_t i = i_begin + gid;
+    unsigned long long cnt = 0;
+    if (i < i_end && i > 0) {
+        const double ri = r[i];
+        int64_t a = 0, len = i;            // a = first j in [0, i) with ri - r[j] <= hi
+        while (len > 0) {
+            const int64_t half = len >> 1;
+            const bool in = (ri - r[a + half]) <= hi;
+            a = in ? a : a + half + 1;
+            len = in ? half : len - half - 1;
+        }
+        int64_t b = 0;                     // b = first j in [0, i) with not (ri - r[j] >= lo)
+        len = i;
+        while (len > 0) {
+            const int64_t half = len >> 1;
+            const bool ge = (ri - r[b + half]) >= lo;
+            b = ge ? b + half + 1 : b;
+            len = ge ? len - half - 1 : half;
+        }
+        cnt = b > a ? (unsigned long long)(b - a) : 0ull;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    __shared__ unsigned long long wsum[kIB / 64];
+    __shared__ int wbad[kIB / 64];
+    const bool any_bad = __ballot(bad) != 0;
+    if ((tid & 63) == 0) { wsum[tid >> 6] = cnt; wbad[tid >> 6] = any_bad ? 1 : 0; }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long tot = 0;
+        int b = 0;
+        for (int w = 0; w < kIB / 64; ++w) { tot += wsum[w]; b |= wbad[w]; }
+        if (tot) atomicAdd(out, tot);
+        if (b) atomicOr(out + 1, 1ull);
+    }
+}
+
 // Per-device scratch kept between calls (stream, device buffers): creating a
 // stream and two allocations per call cost ~4 ms, ten times the reference's CPU
 // time for a 1,000-bin chromosome.  Guarded by a mutex: calls on one device
@@ -113,9 +169,9 @@ int bb_band_count_rows(const double *regions, int64_t n, int32_t low, int32_t hi
     std::lock_guard<std::mutex> lock(c->mu);
     hipError_t e = hipSuccess;
     if (!c->stream) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess && !c->d_out) e = hipMalloc((void **)&c->d_out, sizeof(unsigned long long));
+    if (e == hipSuccess && !c->d_out) e = hipMalloc((void **)&c->d_out, 2 * sizeof(unsigned long long));
     if (e == hipSuccess && !c->h_out)
-        e = hipHostMalloc((void **)&c->h_out, sizeof(unsigned long long), hipHostMallocDefault);
+        e = hipHostMalloc((void **)&c->h_out, 2 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess && c->cap < n) {
         (void)hipFree(c->d_r);
         c->d_r = nullptr;
@@ -127,9 +183,32 @@ int bb_band_count_rows(const double *regions, int64_t n, int32_t low, int32_t hi
         return bb::fail(BB_ERR_NOMEM, std::string("bb_band_count: ") + hipGetErrorString(e));
     hipStream_t st = c->stream;
     e = hipMemcpyAsync(c->d_r, regions, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st);
+    const int64_t rows = i_end - i_begin;
+    // sorted input (every ContactMap's regions): two binary searches per row; the kernel
+    // reports in out[1] if the order it relies on does not hold.  BB_BAND_SORTED=0: never.
+    const char *env = getenv("BB_BAND_SORTED");
+    bool brute = env && atoi(env) == 0;
+    if (!brute) {
+        if (e == hipSuccess) e = hipMemsetAsync(c->d_out, 0, 2 * sizeof(unsigned long long), st);
+        if (e == hipSuccess) {
+            const int64_t want = std::max<int64_t>(rows, std::min<int64_t>(n, 1 << 16));
+            e = bb::launch(band_count_sorted_kernel, dim3((unsigned)((want + kIB - 1) / kIB)), dim3(kIB),
+                           0, st, c->d_r, n, (double)low, (double)high, i_begin, i_end, c->d_out);
+        }
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(c->h_out, c->d_out, 2 * sizeof(unsigned long long),
+                               hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess)
+            return bb::fail(BB_ERR_HIP, std::string("bb_band_count: ") + hipGetErrorString(e));
+        if (c->h_out[1] == 0) {
+            *count = (int64_t)c->h_out[0];
+            return BB_OK;
+        }
+        brute = true;                      // not sorted (or not finite): the double loop
+    }
     if (e == hipSuccess) e = hipMemsetAsync(c->d_out, 0, sizeof(unsigned long long), st);
     if (e == hipSuccess) {
-        const int64_t rows = i_end - i_begin;
         const dim3 grid((unsigned)((i_end - 1 + kJC - 1) / kJC), (unsigned)((rows + kIB - 1) / kIB));
         if (grid.y > 65535u) {
             e = hipErrorInvalidValue;

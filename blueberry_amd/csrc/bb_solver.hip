@@ -17,6 +17,10 @@
 #include <type_traits>
 #include <vector>
 
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "bb_comm.h"
 #include "bb_common.h"
 #include "bb_solver_kernels.h"
@@ -35,6 +39,7 @@ struct bb_solver {
 
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool stream_stuck = false;     // behind a collective that cannot be aborted: never waited on again
 
     void *d_units = nullptr, *d_X = nullptr, *d_V = nullptr, *d_part = nullptr, *d_exch = nullptr;
     double momentum = 0.0;
@@ -65,6 +70,7 @@ struct bb_solver {
     bool have_wish = false, have_coords = false, grad_pending = false;
 
     bb::Rccl::Comm comm = nullptr;  // direct RCCL path (bb_solver_comm_init), else null
+    bool comm_cached = false;       // the communicator belongs to the process-wide cache
 
     // peer exchange (bb_solver_peer_*)
     void *peer_arena = nullptr;             // this rank's receive arena (uncached)
@@ -97,6 +103,8 @@ struct bb_solver {
 };
 
 namespace {
+
+void comm_release(bb_solver *s, bool destroy);   // the communicator cache, further down
 
 constexpr int64_t kHistCap = 1 << 20;
 constexpr size_t kMaxTimedLaunches = 4096;
@@ -776,8 +784,13 @@ int bb_solver_create(bb_solver **out, int64_t n_bins, int dtype, int device, int
 int bb_solver_destroy(bb_solver *s) {
     if (!s) return BB_OK;
     hipSetDevice(s->device);
-    if (s->stream || !s->own_stream) hipStreamSynchronize(s->stream);
-    if (s->comm) bb::rccl().CommDestroy(s->comm);
+    if (!s->stream_stuck && (s->stream || !s->own_stream)) hipStreamSynchronize(s->stream);
+    if (s->comm) {
+        bb::Rccl::Comm c = s->comm;
+        const bool cached = s->comm_cached;
+        comm_release(s, /*destroy=*/false);  // a cached communicator goes back to the cache
+        if (!cached) bb::rccl().CommDestroy(c);
+    }
     for (void *m : s->peer_opened) hipIpcCloseMemHandle(m);
     hipFree(s->peer_arena);
     hipFree(s->d_peer_table);
@@ -787,7 +800,9 @@ int bb_solver_destroy(bb_solver *s) {
     hipFree(s->d_arena);
     if (s->own_exch) hipFree(s->d_exch);
     hipFree(s->d_mv_in);
-    if (s->own_stream && s->stream) bb::release_stream(s->device, s->stream);
+    // (a stream abandoned behind a hung collective is not returned to the pool: the pool
+    // synchronises what it takes back)
+    if (s->own_stream && s->stream && !s->stream_stuck) bb::release_stream(s->device, s->stream);
     delete s;
     // tear-down is best effort (a free can fail when a peer process has already gone
     // away): whatever it left in the thread's error word is consumed here
@@ -1084,6 +1099,77 @@ int bb_comm_unique_id(void *id_out) {
     return BB_OK;
 }
 
+// The library's communicators outlive the solvers that use them: ncclCommInitRank costs
+// 0.1-1 s and every multi-rank fit() used to pay it (round 2 made a fresh communicator per
+// fit and destroyed it with the solver).  One communicator per (device, rank, world) is
+// kept for the life of the process; a solver borrows it (bb_solver_comm_attach) and gives
+// it back when it is destroyed.  While one solver holds it, another one gets a
+// communicator of its own (a communicator must not serve two streams at once).
+namespace {
+struct CachedComm {
+    bb::Rccl::Comm comm = nullptr;
+    bool in_use = false;
+};
+std::mutex g_comm_mu;
+std::map<std::tuple<int, int, int>, CachedComm> g_comm_cache;
+
+void comm_release(bb_solver *s, bool destroy) {
+    if (!s->comm) return;
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    if (s->comm_cached) {
+        auto it = g_comm_cache.find(std::make_tuple(s->device, s->rank, s->world));
+        if (it != g_comm_cache.end() && it->second.comm == s->comm) {
+            if (destroy)
+                g_comm_cache.erase(it);       // a suspect communicator is not handed out again
+            else
+                it->second.in_use = false;
+        }
+    }
+    s->comm = nullptr;
+    s->comm_cached = false;
+}
+}  // namespace
+
+int bb_comm_cached(int device, int rank, int world, int *available) {
+    BB_REQUIRE(available != nullptr, "bb_comm_cached: available is NULL");
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    auto it = g_comm_cache.find(std::make_tuple(device, rank, world));
+    *available = (it != g_comm_cache.end() && it->second.comm && !it->second.in_use) ? 1 : 0;
+    return BB_OK;
+}
+
+int bb_solver_comm_attach(bb_solver *s) {
+    BB_REQUIRE(s != nullptr, "bb_solver_comm_attach: solver is NULL");
+    if (s->comm) return bb::fail(BB_ERR_STATE, "bb_solver_comm_attach: communicator already made");
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    auto it = g_comm_cache.find(std::make_tuple(s->device, s->rank, s->world));
+    if (it == g_comm_cache.end() || !it->second.comm || it->second.in_use)
+        return bb::fail(BB_ERR_STATE, "bb_solver_comm_attach: no free cached communicator");
+    it->second.in_use = true;
+    s->comm = it->second.comm;
+    s->comm_cached = true;
+    return BB_OK;
+}
+
+int bb_solver_comm_detach(bb_solver *s) {
+    BB_REQUIRE(s != nullptr, "bb_solver_comm_detach: solver is NULL");
+    if (s->comm && !s->comm_cached)
+        return bb::fail(BB_ERR_STATE, "bb_solver_comm_detach: the communicator is the solver's own");
+    comm_release(s, /*destroy=*/false);
+    return BB_OK;
+}
+
+int bb_comm_cache_clear(void) {
+    const bb::Rccl &R = bb::rccl();
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    for (auto it = g_comm_cache.begin(); it != g_comm_cache.end();) {
+        if (it->second.in_use) { ++it; continue; }
+        if (it->second.comm && R.ok) R.CommDestroy(it->second.comm);
+        it = g_comm_cache.erase(it);
+    }
+    return BB_OK;
+}
+
 int bb_solver_comm_init(bb_solver *s, const void *unique_id) {
     BB_REQUIRE(s != nullptr && unique_id != nullptr, "bb_solver_comm_init: NULL argument");
     if (s->comm) return bb::fail(BB_ERR_STATE, "bb_solver_comm_init: communicator already made");
@@ -1097,6 +1183,17 @@ int bb_solver_comm_init(bb_solver *s, const void *unique_id) {
         s->comm = nullptr;
         return bb::fail(BB_ERR_HIP, std::string("ncclCommInitRank: ") + R.GetErrorString(rc));
     }
+    {
+        // into the cache, unless another solver holds this key's entry right now
+        std::lock_guard<std::mutex> lock(g_comm_mu);
+        CachedComm &c = g_comm_cache[std::make_tuple(s->device, s->rank, s->world)];
+        if (!c.in_use) {
+            if (c.comm && c.comm != s->comm) R.CommDestroy(c.comm);   // a stale one: replaced
+            c.comm = s->comm;
+            c.in_use = true;
+            s->comm_cached = true;
+        }
+    }
     return BB_OK;
 }
 
@@ -1105,11 +1202,22 @@ int bb_solver_comm_abort(bb_solver *s) {
     if (!s->comm) return BB_OK;
     const bb::Rccl &R = bb::rccl();
     bb::Rccl::Comm c = s->comm;
-    s->comm = nullptr;
+    comm_release(s, /*destroy=*/true);       // out of the cache: it is not handed out again
     s->grad_pending = false;
+    if (!R.CommAbort) {
+        // No ncclCommAbort in this librccl.  ncclCommDestroy waits for the communicator's
+        // outstanding work -- on a communicator that may sit in a collective a peer never
+        // joined that is for ever, which is exactly what this call exists to end.  The
+        // communicator is leaked instead and the solver's stream is marked stuck: nothing
+        // synchronises on it any more (bb_solver_destroy, the stream pool).
+        s->stream_stuck = true;
+        return bb::fail(BB_ERR_STATE,
+                        "bb_solver_comm_abort: this librccl has no ncclCommAbort; the "
+                        "communicator was leaked and the solver's stream abandoned");
+    }
     // ncclCommAbort ends the communicator's in-flight kernels, so a stream that is
     // stuck behind a collective a peer never joined drains again
-    const int rc = R.CommAbort ? R.CommAbort(c) : R.CommDestroy(c);
+    const int rc = R.CommAbort(c);
     if (rc != bb::Rccl::kSuccess)
         return bb::fail(BB_ERR_HIP, std::string("ncclCommAbort: ") + R.GetErrorString(rc));
     return BB_OK;

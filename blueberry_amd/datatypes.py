@@ -22,8 +22,9 @@ Deviations from the reference, all deliberate:
     `normalize()` raises instead of indexing out of bounds --
     `keep_stale=True` restores the old behaviour.  The matrix it leaves is bit
     for bit the reference's (goldens `cm*_filter_*`).
-  * `matrix` is a lazily fetched attribute: the matrix lives in HBM (class
-    docstring); `to_host()`, `marginals()`, `from_triples()` are additions.
+  * `matrix` is a lazily fetched attribute, read-only while the matrix lives in HBM
+    (class docstring); `to_host()`, `host_matrix()`, `marginals()`, `from_triples()`
+    are additions.
   * `normalize` raises ZeroDivisionError up front when a divisor would be 0
     (the reference raises from inside the loop, after modifying part of the
     matrix, because Cython checks float division; golden flag
@@ -40,6 +41,20 @@ KR_NORM = RAO + ("data/Rao-Cell2014/rawFromGEO/{0}/{2}kb_resolution_intrachromos
                  "MAPQGE30/chr{1}_{2}kb.KRnorm")
 KR_EXP = RAO + ("data/Rao-Cell2014/rawFromGEO/{0}/{2}kb_resolution_intrachromosomal/chr{1}/"
                 "MAPQGE30/chr{1}_{2}kb.KRexpected")
+
+
+def _pick_device(device):
+    """An explicit index wins; else this rank's own GPU inside a torch.distributed job
+    (LOCAL_RANK, the rule of StructureSolver._pick_device and band.pick_device), else 0.
+    torch is only looked at if the process has imported it already."""
+    if device is not None:
+        return int(device)
+    import os
+    import sys
+    td = sys.modules.get("torch.distributed")
+    if td is not None and td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+        return int(os.environ.get("LOCAL_RANK", "0"))
+    return 0
 
 
 def scatter_triples(triples, resolution, n_bins, device=0):
@@ -133,6 +148,17 @@ class _DeviceMatrix(object):
             pass
 
 
+class EigenNoConvergence(RuntimeError):
+    """`ContactMap.eigenvector` used up `max_matvecs` before its residual reached the
+    tolerance (the counterpart of scipy's ArpackNoConvergence, which the reference's
+    `eigsh` call raises, `blueberry/datatypes.pyx:234`).  `.eigenvalue`, `.eigenvector`:
+    the pair found so far."""
+
+    def __init__(self, msg, eigenvalue, eigenvector):
+        RuntimeError.__init__(self, msg)
+        self.eigenvalue, self.eigenvector = eigenvalue, eigenvector
+
+
 class ContactMap(object):
     """This is a contact map for Hi-C datasets.
 
@@ -157,18 +183,19 @@ class ContactMap(object):
     the constructor scatters the triples on the device, `normalize()` and `filter()`
     work on the resident matrix in place, and `StructureSolver.fit(contact_map)` packs
     it device to device -- no (n_bins+1)^2 host transfer anywhere on that path.
-    `matrix` is fetched lazily: reading the attribute downloads the matrix (once)
-    and, because the caller may then write into the array, makes the host copy the
-    authoritative one -- the next device operation uploads it again.  `to_host()`
-    returns a private copy and leaves the device copy authoritative.
+    `matrix` is fetched lazily and is a READ-ONLY copy while the matrix lives in HBM: a read
+    does not cost the residency.  `to_host()` returns a private writable copy and leaves the
+    device copy authoritative; `host_matrix()` / `cm.matrix = m` make a host array the
+    authoritative one.  `device=None` means this rank's own GPU inside a torch.distributed
+    job (LOCAL_RANK, as `StructureSolver` picks it), else device 0.
     """
 
-    def __init__(self, celltype, chromosome, resolution=1000, device=0):
+    def __init__(self, celltype, chromosome, resolution=1000, device=None):
         import pandas
         self.resolution = int(resolution)
         self.chromosome = chromosome
         self.celltype = celltype
-        self.device = int(device)
+        self.device = _pick_device(device)
         kb = self.resolution // 1000
         self.filename = RAW_DIR.format(celltype, chromosome, kb)
         self._KRnorm = numpy.atleast_1d(numpy.loadtxt(KR_NORM.format(celltype, chromosome, kb)))
@@ -177,7 +204,7 @@ class ContactMap(object):
         data = pandas.read_csv(self.filename, delimiter="\t", engine="c", dtype="float64",
                                header=None).values
         data = _nan_to_num(data)
-        self._host = None
+        self._host = self._view = None
         self._dev, self.regions = _DeviceMatrix.from_triples(data, self.resolution, self.n_bins,
                                                              self.device, want_regions=True)
         self.regions.sort()
@@ -185,23 +212,43 @@ class ContactMap(object):
     # -- where the matrix lives ------------------------------------------
     @property
     def matrix(self):
-        if self._host is None:
-            self._host = self._dev.to_host()
-        # the caller may write into it: from here on the host copy is the truth
-        if self._dev is not None:
-            self._dev.close()
-            self._dev = None
-        return self._host
+        """The (n_bins+1)^2 float64 matrix.  While the matrix lives in HBM this is a
+        READ-ONLY host copy (fetched once, dropped when a device operation changes the
+        matrix): looking at `cm.matrix.shape`, `.sum()` or a cell costs one download, not
+        the residency.  Round 2 handed out a writable array and, because the caller might
+        write into it, gave the device copy up on every read -- 5 GB down and 5 GB up again
+        around a `cm.matrix[0, 0]` at chr1@10kb.  To CHANGE the matrix assign a new one
+        (`cm.matrix = m`) or ask for the writable host copy (`cm.host_matrix()`); both
+        make the host array the authoritative one, as the reference's attribute is
+        (`blueberry/datatypes.pyx:85`)."""
+        if self._dev is None:
+            return self._host
+        if self._view is None:
+            v = self._dev.to_host()
+            v.flags.writeable = False
+            self._view = v
+        return self._view
 
     @matrix.setter
     def matrix(self, value):
         self._host = value
+        self._view = None
         if self._dev is not None:
             self._dev.close()
             self._dev = None
 
+    def host_matrix(self):
+        """The matrix as a writable host array that is from now on the authoritative copy
+        (the resident one is given up; the next device operation uploads the array again)."""
+        if self._dev is not None:
+            self._host = self._dev.to_host()
+            self._dev.close()
+            self._dev = None
+        self._view = None
+        return self._host
+
     def to_host(self):
-        """A copy of the matrix; the resident one stays authoritative."""
+        """A private copy of the matrix; the resident one stays authoritative."""
         if self._dev is not None:
             return self._dev.to_host()
         return numpy.array(self._host, dtype=numpy.float64)
@@ -217,9 +264,23 @@ class ContactMap(object):
             m = numpy.ascontiguousarray(self._host, dtype=numpy.float64)
             if m.ndim != 2 or m.shape[0] != m.shape[1]:
                 raise ValueError("matrix must be square")
+            if m.shape[0] == 0:
+                raise ValueError("the contact map is empty (every bin was filtered out)")
             self._dev = _DeviceMatrix.from_host(m, self.device)
             self._host = None
+        self._view = None      # the caller is about to work on (usually: change) the resident matrix
         return self._dev
+
+    # a ContactMap pickles / deep-copies as its host matrix: the device handle is a pointer
+    # into this process's HIP context and means nothing anywhere else
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_host"] = self.to_host()
+        state["_dev"] = state["_view"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
 
     @property
     def shape(self):
@@ -229,7 +290,7 @@ class ContactMap(object):
     # ------------------------------------------------------------------
     @classmethod
     def from_arrays(cls, celltype, chromosome, resolution, contacts, n_bins=None, KRnorm=None,
-                    KRexpected=None, symmetric=True, device=0):
+                    KRexpected=None, symmetric=True, device=None):
         """Create a contact map from numpy arrays.  No files required.
 
         contacts : (n, 3) array of (mid1, mid2, statistic), mid = bin midpoint,
@@ -241,7 +302,7 @@ class ContactMap(object):
         self.resolution = int(resolution)
         self.chromosome = chromosome
         self.celltype = celltype
-        self.device = int(device)
+        self.device = _pick_device(device)
         self.filename = ""
         contacts = numpy.asarray(contacts, dtype=numpy.float64)
         if contacts.ndim != 2 or contacts.shape[1] != 3:
@@ -261,7 +322,7 @@ class ContactMap(object):
             m[b1[k], b2[k]] = contacts[k, 2]
             if symmetric:
                 m[b2[k], b1[k]] = contacts[k, 2]
-        self._host, self._dev = m, None
+        self._host, self._dev, self._view = m, None, None
         self.regions = numpy.union1d(contacts[:, 0], contacts[:, 1])
         self._KRnorm = None if KRnorm is None else numpy.asarray(KRnorm, dtype=numpy.float64)
         self._KRexpected = (None if KRexpected is None
@@ -270,15 +331,15 @@ class ContactMap(object):
 
     @classmethod
     def from_matrix(cls, matrix, resolution=1000, celltype="", chromosome=0, KRnorm=None,
-                    KRexpected=None, device=0):
+                    KRexpected=None, device=None):
         """Wrap an existing dense symmetric ((n_bins+1)^2) float64 matrix."""
         self = cls.__new__(cls)
         m = numpy.ascontiguousarray(matrix, dtype=numpy.float64)
         if m.ndim != 2 or m.shape[0] != m.shape[1] or m.shape[0] < 1:
             raise ValueError("matrix must be square")
         self.resolution, self.chromosome, self.celltype = int(resolution), chromosome, celltype
-        self.device, self.filename = int(device), ""
-        self._host, self._dev = m, None
+        self.device, self.filename = _pick_device(device), ""
+        self._host, self._dev, self._view = m, None, None
         self.n_bins = m.shape[0] - 1
         self.regions = numpy.arange(self.n_bins, dtype=numpy.float64) * self.resolution
         self._KRnorm = None if KRnorm is None else numpy.asarray(KRnorm, dtype=numpy.float64)
@@ -288,16 +349,16 @@ class ContactMap(object):
 
     @classmethod
     def from_triples(cls, triples, resolution, n_bins, KRnorm=None, KRexpected=None, celltype="",
-                     chromosome=0, device=0):
+                     chromosome=0, device=None):
         """The file constructor without the files: Rao-format (n, 3) rows
         [pos_i, pos_j, count] (what `__init__` reads, pyx:100-102), scattered on the
         device; the matrix is never built on the host."""
         self = cls.__new__(cls)
         self.resolution, self.chromosome, self.celltype = int(resolution), chromosome, celltype
-        self.device, self.filename = int(device), ""
+        self.device, self.filename = _pick_device(device), ""
         data = _nan_to_num(triples)
         self.n_bins = int(n_bins)
-        self._host = None
+        self._host = self._view = None
         self._dev, self.regions = _DeviceMatrix.from_triples(data, self.resolution, self.n_bins,
                                                              self.device, want_regions=True)
         self._KRnorm = None if KRnorm is None else numpy.asarray(KRnorm, dtype=numpy.float64)
@@ -308,6 +369,8 @@ class ContactMap(object):
     # ------------------------------------------------------------------
     def marginals(self):
         """`matrix.sum(axis=0)` of the resident matrix (pyx:140), bit for bit."""
+        if self.shape[0] == 0:
+            return numpy.zeros(0)
         dev = self._resident()
         out = numpy.empty(dev.d, dtype=numpy.float64)
         _lib.check(dev._lib.bb_cm_marginals(dev._h, _lib.as_f64_ptr(out)), "bb_cm_marginals")
@@ -319,6 +382,8 @@ class ContactMap(object):
         In place, returns None (`blueberry/datatypes.pyx:122-141`); runs on the GPU on
         the resident matrix: column sums in numpy's summation order, prefix-sum
         compaction, gather."""
+        if self.shape[0] == 0:
+            return                     # nothing left to filter (numpy: an empty index list)
         dev = self._resident()
         d = dev.d
         keep = numpy.zeros(d, dtype=numpy.uint8)
@@ -369,6 +434,8 @@ class ContactMap(object):
         the fp64 matrix cores, scaled by the diagonal and clipped to [-1, 1] in numpy's
         order of operations (`bb_cm_correlation`).  Equal to numpy to rounding.
         `correlation_tflops_` holds the rate of the Gram kernel afterwards."""
+        if self.shape[0] == 0:
+            return
         dev = self._resident()
         tf = _lib.c_dbl()
         _lib.check(dev._lib.bb_cm_correlation(dev._h, tf), "bb_cm_correlation")
@@ -403,6 +470,13 @@ class ContactMap(object):
                                               int(max_matvecs), used, res), "bb_cm_eigenvector")
         self.eigenvalue_, self.eigen_matvecs_, self.eigen_residual_ = (
             float(lam.value), int(used.value), float(res.value))
+        if self.eigen_residual_ > float(tol) * abs(self.eigenvalue_) and self.eigen_matvecs_ >= max_matvecs:
+            # scipy's eigsh raises ArpackNoConvergence here; the unconverged pair travels
+            # with the exception as ARPACK's does
+            raise EigenNoConvergence(
+                "eigenvector: residual %.3e after %d matrix-vector products (tol %.1e x |%.6e|)"
+                % (self.eigen_residual_, self.eigen_matvecs_, tol, self.eigenvalue_),
+                self.eigenvalue_, vec)
         return vec
 
 

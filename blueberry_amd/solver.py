@@ -205,6 +205,20 @@ class HipEngine(object):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return bool(flag.item())
 
+    # the library's communicator cache (bb_comm_cached / bb_solver_comm_attach / _detach):
+    # `comm_reuse` below drives these three
+    def _comm_cached(self):
+        import ctypes
+        have = ctypes.c_int(0)
+        self._lib.bb_comm_cached(self.device, self.rank, self.world, ctypes.byref(have))
+        return bool(have.value)
+
+    def _comm_attach(self):
+        return self._lib.bb_solver_comm_attach(self._h) == _lib.BB_OK
+
+    def _comm_detach(self):
+        self._lib.bb_solver_comm_detach(self._h)
+
     def iterate_dist(self, iters, lr):
         """`iters` x { grad, RCCL all-reduce, apply }, all enqueued by one C call."""
         _lib.check(self._lib.bb_solver_iterate_dist(self._h, int(iters), float(lr)),
@@ -527,7 +541,8 @@ class StructureSolver(object):
         resident = getattr(matrix, "is_resident", False)
         sparse = hasattr(matrix, "row") and not resident
         if n < 2:
-            raise ValueError("need at least 2 bins")
+            raise ValueError("need at least 2 bins (the contact map is empty)" if n == 0 else
+                             "need at least 2 bins")
         rank, world = _dist_state(self.distributed)
         lr = 1.0 / (2.0 * n) if self.lr == "auto" else float(self.lr)
         if init is None and self.init == "random":
@@ -544,19 +559,30 @@ class StructureSolver(object):
         try:
             if resident:
                 dev = matrix._resident()
-                if dev.device != eng.device:
-                    raise ValueError("the ContactMap lives on device %d, the solver runs on %d"
-                                     % (dev.device, eng.device))
-                eng.set_wish_from_cm(dev, self.kind, self.alpha)
+                if dev.device == eng.device:
+                    eng.set_wish_from_cm(dev, self.kind, self.alpha)
+                else:
+                    # the map lives on another GPU than this rank's solver (a ContactMap made
+                    # with an explicit device): through the host once, like a plain matrix
+                    eng.set_wish_dense(matrix.to_host(), self.kind, self.alpha)
             elif sparse:
                 eng.set_wish_sparse(rows, cols, vals, self.kind, self.alpha, KRnorm, KRexpected)
             else:
                 eng.set_wish_dense(matrix, self.kind, self.alpha)
-            if init is None and world == 1 and hasattr(eng, "spectral_init_device"):
-                # 'spectral' on one rank: the whole block power iteration stays on the device
+            on_device = False
+            if init is None and world == 1 and n >= 4 and hasattr(eng, "spectral_init_device"):
+                # 'spectral' on one rank: the whole block power iteration stays on the device.
+                # Its Cholesky-QR needs an iterate of full column rank; maps it cannot take --
+                # fewer than 4 bins (centring leaves at most 2 directions), an empty or
+                # unconstrained map -- go through the host form below, which several ranks use
+                # anyway, so the same input runs on every world size.
                 v0 = numpy.random.default_rng(self.seed).standard_normal((n, 3))
-                eng.spectral_init_device(40, v0)
-            else:
+                try:
+                    eng.spectral_init_device(40, v0)
+                    on_device = True
+                except RuntimeError:
+                    pass
+            if not on_device:
                 if init is None:                   # 'spectral', several ranks / test engines
                     init = spectral_init(eng, n, world, seed=self.seed)
                 eng.set_coords(init)
@@ -719,6 +745,31 @@ def _trial_leg(eng, name, step, lr, x0, iters):
     return True, box["x1"], box["dt"]
 
 
+def comm_reuse(eng):
+    """Borrow the communicator an earlier solver of this job made: the library keeps one
+    per (device, rank, world) for the life of the process, so only the first multi-rank
+    fit() pays ncclCommInitRank (0.1-1 s; round 2 made and destroyed one per fit).
+    Collective, and the same on every rank by construction: the ranks first agree that
+    EVERY one of them holds a free cached communicator, then that every attach worked;
+    otherwise nobody uses the cache and `comm_setup` makes a fresh one everywhere."""
+    if not _all_ranks(eng._comm_cached()):
+        return False
+    ok = eng._comm_attach()
+    if not _all_ranks(ok):
+        if ok:
+            eng._comm_detach()
+        return False
+    return True
+
+
+def _comm_get(eng):
+    """The library's communicator for this engine: the one an earlier fit() of this job
+    left in the library's cache (`comm_reuse`), else a new one (`comm_setup`).  Collective."""
+    if hasattr(eng, "_comm_cached") and comm_reuse(eng):
+        return True
+    return eng.comm_setup()
+
+
 def select_exchange(eng, lr, trial=False):
     """Decide, once per engine and identically on every rank, how the partial
     gradients are summed over the ranks.  Collective.
@@ -757,9 +808,9 @@ def select_exchange(eng, lr, trial=False):
     elif want == "torch":
         state = "torch"
     elif want == "rccl" or not trial:
-        state = "rccl" if eng.comm_setup() else "torch"
+        state = "rccl" if _comm_get(eng) else "torch"
     else:
-        have_rccl = eng.comm_setup()
+        have_rccl = _comm_get(eng)
         have_peer = eng.peer_setup()
         if have_rccl and have_peer:
             x0 = eng.get_coords()

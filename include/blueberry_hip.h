@@ -193,6 +193,18 @@ BB_API int bb_solver_comm_world(const bb_solver *s, int *world);
  * joined, so the solver's stream drains again.  The solver falls back to
  * bb_solver_grad / caller's all-reduce / bb_solver_apply. */
 BB_API int bb_solver_comm_abort(bb_solver *s);
+/* The communicator a bb_solver_comm_init makes is kept by the library for the life of the
+ * process, one per (device, rank, world); a solver borrows it and hands it back when it is
+ * destroyed.  Later solvers of the same job skip ncclCommInitRank:
+ *   bb_comm_cached          *available = 1 if a free communicator for this key is held
+ *   bb_solver_comm_attach   borrow it (every rank of the job must take the same path: agree
+ *                           on `available` first -- the Python wrapper all-reduces a MIN)
+ *   bb_solver_comm_detach   hand a borrowed one back without using it
+ *   bb_comm_cache_clear     destroy the communicators no solver holds (ncclCommDestroy) */
+BB_API int bb_comm_cached(int device, int rank, int world, int *available);
+BB_API int bb_solver_comm_attach(bb_solver *s);
+BB_API int bb_solver_comm_detach(bb_solver *s);
+BB_API int bb_comm_cache_clear(void);
 
 /* Peer exchange: a one-shot all-reduce over xGMI written into the solver's own
  * kernels -- no collective library in the loop.  Every rank owns a receive

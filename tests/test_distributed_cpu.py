@@ -243,6 +243,82 @@ def test_trial_with_a_rank_that_fails_before_its_collective(fail_leg, expect, ab
             assert fail_leg in trial["error"]
 
 
+def _reuse_worker(rank, world, port, q):
+    """Three 'fits' of one job: select_exchange on three fresh engines whose communicator
+    cache is a dict that plays the library's (bb_comm_cached / _attach / _detach).  Before the
+    third, rank 1 loses its cached communicator."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.pop("BB_COMM", None)
+        os.environ.pop("BB_COMM_TRIAL", None)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from blueberry_amd import solver
+        from tests._engines import ScriptedRankEngine
+
+        cache = {}                      # the library's process-wide cache, played
+
+        class Engine(ScriptedRankEngine):
+            setups = 0
+
+            def comm_setup(self):
+                Engine.setups += 1
+                cache["comm"] = "made by fit %d" % Engine.setups
+                self.comm = cache["comm"]
+                return True
+
+            def _comm_cached(self):
+                return "comm" in cache
+
+            def _comm_attach(self):
+                self.comm = cache["comm"]
+                return True
+
+            def _comm_detach(self):
+                self.comm = None
+
+        # select_exchange must take its RCCL branch; the agreement (all_gather_object) runs
+        # over the real gloo group
+        dist.get_backend = lambda *a, **k: "nccl"
+        out = []
+        for fit in range(3):
+            if fit == 2 and rank == 1:
+                cache.clear()
+            e = Engine(rank, world, None)
+            state = solver.select_exchange(e, 0.5)
+            out.append((state, Engine.setups, e.comm))
+        q.put((rank, out))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "FAILED " + traceback.format_exc()))
+
+
+def test_two_fits_make_one_communicator():
+    """every multi-rank fit() made a fresh RCCL communicator.  Now
+    the first fit of a job makes it (comm_setup), later ones borrow it from the library's
+    cache (solver.comm_reuse) -- and when one rank has lost its copy, EVERY rank makes a
+    new one: the ranks agree before anybody attaches."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reuse_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    for rank in (0, 1):
+        assert not isinstance(results[rank], str), results[rank]
+        (s1, n1, c1), (s2, n2, c2), (s3, n3, c3) = results[rank]
+        assert (s1, s2, s3) == ("rccl", "rccl", "rccl")
+        assert (n1, n2) == (1, 1) and c2 == c1 == "made by fit 1"     # the second fit reused it
+        assert n3 == 2 and c3 == "made by fit 2"                       # both ranks, not just rank 1
+
+
 def test_select_exchange_overrides(one_rank_group, monkeypatch):
     from blueberry_amd import solver
     monkeypatch.setattr(one_rank_group, "get_backend", lambda *a, **k: "nccl")

@@ -55,6 +55,57 @@ def test_band_count_closed_form_large():
     assert bb.count_band_regions(r) == sum(n - d for d in range(5, 2001))
 
 
+def _band_both_paths(r, **kw):
+    """(sorted fast path -- falls back by itself when its order check fails --, double loop)"""
+    import os
+    fast = bb.count_band_regions(r, **kw)
+    os.environ["BB_BAND_SORTED"] = "0"
+    try:
+        brute = bb.count_band_regions(r, **kw)
+    finally:
+        del os.environ["BB_BAND_SORTED"]
+    return fast, brute
+
+
+@pytest.mark.parametrize("name", band_cases())
+def test_band_count_golden_on_the_double_loop_too(name):
+    z = _oracle.golden("band_count")
+    fast, brute = _band_both_paths(z["in_" + name])
+    assert fast == brute == int(z["out_" + name])
+
+
+def test_band_count_sorted_path_edge_values(oracle):
+    """Sorted input takes two binary searches per row (bb_band.hip); it must give the double
+    loop's count bit for bit (blueberry.pyx:86-89): duplicates, inclusive bounds hit exactly,
+    fractional positions whose differences round, a NaN / an inf / one inversion anywhere
+    (the kernel's own order check sends those to the double loop)."""
+    rng = numpy.random.default_rng(11)
+    base = numpy.sort(rng.integers(0, 4000, 3000) * 2500.0)          # many duplicates
+    cases = {"duplicates": base,
+             "exact_bounds": numpy.array([0.0, 25000.0, 25000.0, 50000.0, 1.0e7, 1.0e7 + 25000.0]),
+             "fractional": numpy.sort(rng.random(4000) * 3.0e7),
+             "tiny_steps": numpy.cumsum(rng.random(3000) * 1e-3) + 1e9,
+             "one_inversion": numpy.concatenate([base[:1500], base[1499:1498:-1], base[1500:]]),
+             "nan_inside": numpy.where(numpy.arange(3000) == 777, numpy.nan, base),
+             "inf_at_end": numpy.concatenate([base, [numpy.inf]]),
+             "minus_inf_first": numpy.concatenate([[-numpy.inf], base]),
+             "negative": numpy.sort(rng.random(2000) * 3.0e7) - 1.5e7}
+    for name, r in cases.items():
+        want = oracle.count_band_regions(r)
+        fast, brute = _band_both_paths(r)
+        assert fast == brute == want, (name, fast, brute, want)
+
+
+def test_band_count_genome_10kb_size_both_paths():
+    """BASELINE config 5's size: 309,568 bins at 10 kb.  Closed form; the sorted path and the
+    double loop agree."""
+    n = 309568
+    r = numpy.arange(n) * 10000.0 + 5000.0
+    want = sum(n - d for d in range(3, 1001))            # 30 kb .. 10 Mb apart
+    fast, brute = _band_both_paths(r)
+    assert fast == brute == want
+
+
 def test_band_count_converts_non_float64():
     assert bb.count_band_regions(list(range(0, 500000, 50000))) == \
         bb.count_band_regions(numpy.arange(0, 500000, 50000, dtype=numpy.int32))
@@ -1320,3 +1371,79 @@ def test_early_stop_on_the_device_paths(dtype, solver_path):
     assert numpy.array_equal(early.stress_, full.stress_[:early.n_iter_])
     again = bb.StructureSolver(n_iter=early.n_iter_, **kw).fit(w, init=x0)
     assert numpy.array_equal(again.structure_, early.structure_)
+
+
+# ---- residency survives a read --------------------------------
+def test_reading_matrix_keeps_the_resident_copy(monkeypatch):
+    """`cm.matrix` on a resident map is a read-only host copy; normalize() / filter() / fit()
+    after it work on the matrix that never left HBM: no bb_cm_upload in between (counted
+    through a shim around the library's entry point)."""
+    z = _oracle.golden("contactmap")
+    kr, ke = z["cm2_krnorm"], z["cm2_krexp"]
+    cm = bb.ContactMap.from_triples(z["cm2_triples"], int(z["cm2_resolution"]), kr.shape[0],
+                                    KRnorm=kr, KRexpected=ke)
+    lib = _lib.load()
+    uploads = []
+    real = lib.bb_cm_upload
+    monkeypatch.setattr(lib, "bb_cm_upload", lambda *a: uploads.append(1) or real(*a))
+    m = cm.matrix
+    assert cm.is_resident and not m.flags.writeable
+    assert numpy.array_equal(m, z["cm2_matrix_raw"]) and cm.matrix is m        # fetched once
+    assert cm.matrix.shape == (kr.shape[0] + 1,) * 2 and float(cm.matrix[0, 0]) == m[0, 0]
+    with pytest.raises(ValueError):
+        cm.matrix[0, 0] = 1.0                                  # read-only: assign or host_matrix()
+    cm.normalize()
+    assert cm.is_resident and numpy.array_equal(cm.matrix, z["cm2_matrix_norm"])   # refreshed
+    cm.filter()
+    assert cm.is_resident and uploads == []
+    s = bb.StructureSolver(n_iter=3, dtype="float64").fit(cm)
+    assert cm.is_resident and uploads == [] and numpy.all(numpy.isfinite(s.structure_))
+    # giving the residency up is explicit: a writable array, uploaded again on the next use
+    h = cm.host_matrix()
+    assert not cm.is_resident and h.flags.writeable
+    h *= 2.0
+    assert numpy.array_equal(cm.marginals(), h.sum(axis=0)) and uploads == [1]
+
+
+def test_contactmap_pickles_and_deep_copies_as_its_host_matrix():
+    import copy
+    import pickle
+    z = _oracle.golden("contactmap")
+    kr, ke = z["cm1_krnorm"], z["cm1_krexp"]
+    cm = bb.ContactMap.from_triples(z["cm1_triples"], int(z["cm1_resolution"]), kr.shape[0],
+                                    KRnorm=kr, KRexpected=ke)
+    for other in (copy.deepcopy(cm), pickle.loads(pickle.dumps(cm))):
+        assert cm.is_resident and not other.is_resident
+        assert numpy.array_equal(other.matrix, z["cm1_matrix_raw"]) and other.n_bins == cm.n_bins
+        other.normalize()
+        assert numpy.array_equal(other.to_host(), z["cm1_matrix_norm"])
+    assert numpy.array_equal(cm.to_host(), z["cm1_matrix_raw"])       # the original is untouched
+
+
+def test_filter_that_empties_the_map_leaves_a_usable_object():
+    cm = bb.ContactMap.from_matrix(numpy.ones((5, 5)))
+    cm.filter(threshold=100.0)
+    assert cm.shape == (0, 0) and cm.n_bins == 0
+    assert cm.marginals().shape == (0,) and cm.filter() is None and cm.to_host().shape == (0, 0)
+    cm.host_matrix()
+    assert cm.marginals().shape == (0,) and cm.filter() is None     # host copy, d = 0: no upload
+    with pytest.raises(ValueError, match="empty"):
+        bb.StructureSolver(n_iter=1).fit(cm)
+
+
+def test_eigenvector_reports_no_convergence():
+    """scipy's eigsh raises ArpackNoConvergence when it runs out of iterations
+    (datatypes.pyx:234); a nearly degenerate top pair and a budget of one Lanczos cycle."""
+    d = 400
+    rng = numpy.random.default_rng(3)
+    q, _ = numpy.linalg.qr(rng.standard_normal((d, d)))
+    lam = numpy.linspace(0.0, 1.0, d)
+    lam[-1], lam[-2] = 2.0, 2.0 - 1e-9
+    m = (q * lam) @ q.T
+    m = 0.5 * (m + m.T)
+    cm = bb.ContactMap.from_matrix(m)
+    with pytest.raises(bb.EigenNoConvergence) as err:
+        cm.eigenvector(tol=1e-13, max_matvecs=48)
+    assert abs(err.value.eigenvalue - 2.0) < 1e-6 and err.value.eigenvector.shape == (d,)
+    v = cm.eigenvector(tol=1e-7)                      # a reachable tolerance converges
+    assert abs(cm.eigenvalue_ - 2.0) < 1e-8 and abs(numpy.linalg.norm(v) - 1) < 1e-12
