@@ -25,6 +25,16 @@ struct bb_cm {
     int64_t d = 0;            // current edge (shrinks in filter)
     double *m = nullptr;      // (d, d) row-major, resident
     hipStream_t stream = nullptr;
+    // grow-only scratch of the symmetric matrix-vector product (symv_upper_kernel): the work
+    // list and the row / column partial sums; made by the first product, kept with the handle
+    void *sv_buf = nullptr;
+    size_t sv_bytes = 0;
+    int64_t sv_d = -1;        // the edge the work list was built for
+    int sv_items = 0;
+    // scratch of bb_cm_correlation (centred rows + Gram matrix), kept between calls: the
+    // first touch of a fresh matrix-sized allocation costs 0.2-0.35 s on this platform
+    void *corr_buf = nullptr;
+    size_t corr_bytes = 0;
 };
 
 namespace {
@@ -99,6 +109,74 @@ __global__ __launch_bounds__(kT * 8) void normalize_kernel(double *m, int64_t d,
                                                           : m[kk * d + jj];
             m[kk * d + jj] = nan_to_num(w);
         }
+    }
+}
+
+// The same, 128 x 128 tiles through 132 KB of LDS, persistent workgroups (round 3).  With
+// 32 x 32 tiles a tile row is 256 B of a 200-KB matrix row: on one of the two sides (the
+// tile or its mirror) consecutive accesses of a workgroup open a new DRAM page each, and
+// the kernel ran at 3.0-3.5 TB/s of its 24 B per upper pair (39 % of the 8 TB/s peak).
+// Here every global access of a wave is 512 contiguous bytes of a 1-KiB row segment on
+// BOTH sides; one workgroup of 1024 threads per CU walks a list of tile pairs, and the
+// loads of its next pair are in flight while the mirror of the current one goes out
+// (one workgroup per CU has nobody else to cover its load latency).  Same arithmetic,
+// same order, same bits as normalize_kernel.  Dynamic LDS: tile[128][129] doubles.
+constexpr int kNT = 128;                  // tile edge
+constexpr int kNQ = kNT / 8;              // rows per thread: 1024 threads = 128 columns x 8
+constexpr int kNormLds = kNT * (kNT + 1) * 8;
+__global__ __launch_bounds__(1024) void normalize128_kernel(double *m, int64_t d, int64_t n_bins,
+                                                            const double *__restrict__ kr,
+                                                            const double *__restrict__ krexp,
+                                                            unsigned n_pairs) {
+    extern __shared__ __attribute__((aligned(16))) double ntile[];   // [kNT][kNT + 1]
+    const int tx = threadIdx.x & (kNT - 1), ty = threadIdx.x >> 7;
+    double nv[kNQ];
+    auto fetch = [&](unsigned b) __attribute__((always_inline)) {
+        int TJ, TK;
+        tile_of(b, TJ, TK);
+        const int64_t k = (int64_t)TK * kNT + tx;
+#pragma unroll
+        for (int q = 0; q < kNQ; ++q) {
+            const int64_t j = (int64_t)TJ * kNT + ty + 8 * q;
+            nv[q] = (j < d && k < d) ? __builtin_nontemporal_load(m + j * d + k) : 0.0;
+        }
+    };
+    unsigned b = blockIdx.x;
+    if (b < n_pairs) fetch(b);
+    while (b < n_pairs) {
+        int TJ, TK;
+        tile_of(b, TJ, TK);
+        const int64_t k = (int64_t)TK * kNT + tx;
+        const double krk = k < n_bins ? kr[k] : 1.0;
+        double v[kNQ];
+#pragma unroll
+        for (int q = 0; q < kNQ; ++q) {
+            const int rr = ty + 8 * q;
+            const int64_t j = (int64_t)TJ * kNT + rr;
+            const bool scaled = j < n_bins && k < n_bins && j <= k;
+            v[q] = nv[q];
+            if (scaled) v[q] = v[q] / (kr[j] * krk * krexp[k - j]);
+            if (j < d && k < d && (j <= k || TJ != TK)) m[j * d + k] = nan_to_num(v[q]);
+            ntile[rr * (kNT + 1) + tx] = v[q];
+        }
+        __syncthreads();
+        const unsigned bn = b + gridDim.x;
+        if (bn < n_pairs) fetch(bn);          // in flight while the mirror goes out
+#pragma unroll
+        for (int q = 0; q < kNQ; ++q) {
+            const int rr = ty + 8 * q;
+            // mirrored element: row k' = TK*kNT + rr, column j' = TJ*kNT + tx  (k' > j' region)
+            const int64_t kk = (int64_t)TK * kNT + rr, jj = (int64_t)TJ * kNT + tx;
+            if (kk < d && jj < d && kk > jj) {
+                // row / column n_bins is outside the reference's loop: such a cell keeps its
+                // own value (nobody has written it: phase 1 leaves the lower cells alone)
+                const double w = (kk < n_bins && jj < n_bins) ? ntile[tx * (kNT + 1) + rr]
+                                                              : m[kk * d + jj];
+                m[kk * d + jj] = nan_to_num(w);
+            }
+        }
+        __syncthreads();                      // the tile is free again
+        b = bn;
     }
 }
 
@@ -288,6 +366,127 @@ __global__ __launch_bounds__(256) void symv_kernel(const double *__restrict__ m,
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
         if (lane == 0 && row0 + r < d) y[row0 + r] = v;
+    }
+}
+
+// ---- the same product from the UPPER triangle alone (round 3) ------------------------
+// symv_kernel reads both triangles of a symmetric matrix: 8 B per element where 8 B per
+// PAIR would do (4.25 TB/s, 53 % of peak, on its own accounting).  Here element (i, j),
+// j >= i, is read once and serves both ends, y_i += m_ij x_j and y_j += m_ij x_i -- the
+// pattern of the solver's sweep (kOpMatvec2).  The matrix is taken to be symmetric, as the
+// reference's eigsh call takes it (datatypes.pyx:234) and as every ContactMap is built.
+//   work item   64 rows (4 waves x 16) x up to 4096 columns of the upper triangle; the list
+//               is cut by rows AND columns so that no item is long (a row block alone would
+//               be 0.2 to 12.8 MB at d = 25k and the launch as slow as its longest)
+//   row side    16 per-lane accumulators per wave, reduced across the lanes once per item
+//               -> rowpart[segment][row]
+//   column side a lane owns one column of a 64-column chunk; the 16 rows of the wave add
+//               into one register; after 8 chunks the 4 waves' sums meet in LDS and leave
+//               as one value per column -> colpart[row block][column] (1.5 % of the bytes read)
+//   symv_reduce_kernel adds, per element of y, its row partials (<= d / 4096 + 1) and its
+//               column partials (<= d / 64 + 1) in a fixed order, 8 slices in parallel.
+// All loads are 8 bytes per lane, 512 contiguous bytes per wave: rows of an odd-d matrix
+// start 8 bytes off every other time, and 16 loads of a wave are in flight per chunk.
+constexpr int kSvRows = 64, kSvSeg = 4096, kSvGroup = 8;
+__global__ __launch_bounds__(256, 2) void symv_upper_kernel(const double *__restrict__ m, int64_t d,
+                                                            const double *__restrict__ x,
+                                                            const int2 *__restrict__ items,
+                                                            double *__restrict__ rowpart,
+                                                            double *__restrict__ colpart) {
+    __shared__ double meet[4][kSvGroup][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int2 it = items[blockIdx.x];
+    const int64_t I = it.x, S = it.y;
+    const int64_t row0 = I * kSvRows + wave * 16;
+    const int64_t c_begin = std::max<int64_t>(I * kSvRows, S * kSvSeg);
+    const int64_t c_end = std::min<int64_t>(d, (S + 1) * (int64_t)kSvSeg);
+    double xr[16], racc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        xr[r] = row0 + r < d ? x[row0 + r] : 0.0;
+        racc[r] = 0.0;
+    }
+    for (int64_t cg = c_begin; cg < c_end; cg += 64 * kSvGroup) {
+        double cacc[kSvGroup];
+#pragma unroll
+        for (int g = 0; g < kSvGroup; ++g) {
+            cacc[g] = 0.0;
+            const int64_t c0 = cg + 64 * g;              // chunk start (uniform)
+            if (c0 >= c_end) continue;
+            const int64_t c = c0 + lane;
+            const bool in_c = c < c_end;
+            const double xc = in_c ? x[c] : 0.0;
+            double a[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                a[r] = (in_c && row0 + r < d) ? __builtin_nontemporal_load(m + (row0 + r) * d + c) : 0.0;
+            if (c0 < row0 + 16) {
+                // the chunk crosses this wave's rows: below the diagonal nothing counts, on it
+                // only the row side (the column side would count m_ii x_i twice)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    racc[r] = fma(c >= row0 + r ? a[r] : 0.0, xc, racc[r]);
+                    cacc[g] = fma(c > row0 + r ? a[r] : 0.0, xr[r], cacc[g]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    racc[r] = fma(a[r], xc, racc[r]);
+                    cacc[g] = fma(a[r], xr[r], cacc[g]);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < kSvGroup; ++g) meet[wave][g][lane] = cacc[g];
+        __syncthreads();
+        for (int j = threadIdx.x; j < 64 * kSvGroup; j += 256) {
+            const int g = j >> 6, l = j & 63;
+            const int64_t c = cg + j;
+            if (c < c_end)
+                colpart[I * d + c] = ((meet[0][g][l] + meet[1][g][l]) + meet[2][g][l]) + meet[3][g][l];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        double v = racc[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0 && row0 + r < d) rowpart[S * d + row0 + r] = v;
+    }
+}
+
+// y[c] = sum of c's row partials (segments c / 4096 ..) + its column partials (row blocks
+// 0 .. c / 64), each list in order, cut into 8 slices that are added in slice order.
+__global__ __launch_bounds__(1024) void symv_reduce_kernel(const double *__restrict__ rowpart,
+                                                           const double *__restrict__ colpart,
+                                                           int64_t d, int nseg, double *__restrict__ y) {
+    __shared__ double meet[8][128];
+    const int el = threadIdx.x & 127, sl = threadIdx.x >> 7;
+    const int64_t c = (int64_t)blockIdx.x * 128 + el;
+    double acc = 0.0;
+    if (c < d) {
+        const int64_t s0 = c / kSvSeg, nrow = nseg - s0, ncol = c / kSvRows + 1, n = nrow + ncol;
+        const int64_t per = (n + 7) / 8, k0 = sl * per, k1 = std::min<int64_t>(n, k0 + per);
+        for (int64_t k = k0; k < k1; k += 16) {
+            double v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t kk = k + q;
+                v[q] = kk >= k1 ? 0.0
+                                : (kk < nrow ? rowpart[(s0 + kk) * d + c] : colpart[(kk - nrow) * d + c]);
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc += v[q];
+        }
+    }
+    meet[sl][el] = acc;
+    __syncthreads();
+    if (sl == 0 && c < d) {
+        double t = meet[0][el];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += meet[q][el];
+        y[c] = t;
     }
 }
 
@@ -549,6 +748,86 @@ int cm_check(const bb_cm *cm, const char *who) {
     return bb::enter_device(cm->device);
 }
 
+// y = M x from the upper triangle (symv_upper_kernel + symv_reduce_kernel), x and y on the
+// device, enqueued on the handle's stream.  The work list and the partial-sum buffers are
+// made on first use and whenever the edge has changed (filter), and kept with the handle.
+hipError_t symv_enqueue(bb_cm *cm, const double *dx, double *dy) {
+    const int64_t d = cm->d;
+    const int64_t nrb = (d + kSvRows - 1) / kSvRows, nseg = (d + kSvSeg - 1) / kSvSeg;
+    if (cm->sv_d != d) {
+        std::vector<int2> items;
+        // longest items first: the dispatcher hands them out in order
+        for (int64_t S = nseg - 1; S >= 0; --S)
+            for (int64_t I = 0; I < nrb && I * kSvRows < (S + 1) * (int64_t)kSvSeg; ++I)
+                if (std::max<int64_t>(I * kSvRows, S * kSvSeg) < std::min<int64_t>(d, (S + 1) * (int64_t)kSvSeg))
+                    items.push_back(make_int2((int)I, (int)S));
+        std::stable_sort(items.begin(), items.end(), [&](const int2 &a, const int2 &b) {
+            auto len = [&](const int2 &t) {
+                return std::min<int64_t>(d, (t.y + 1) * (int64_t)kSvSeg) -
+                       std::max<int64_t>((int64_t)t.x * kSvRows, (int64_t)t.y * kSvSeg);
+            };
+            return len(a) > len(b);
+        });
+        const size_t item_bytes = (items.size() * sizeof(int2) + 255) & ~(size_t)255;
+        const size_t need = item_bytes + (size_t)(nseg + nrb) * (size_t)d * 8;
+        if (need > cm->sv_bytes) {
+            (void)hipFree(cm->sv_buf);
+            cm->sv_buf = nullptr;
+            cm->sv_bytes = 0;
+            hipError_t e = hipMalloc(&cm->sv_buf, need);
+            if (e != hipSuccess) return e;
+            cm->sv_bytes = need;
+        }
+        hipError_t e = hipMemcpyAsync(cm->sv_buf, items.data(), items.size() * sizeof(int2),
+                                      hipMemcpyHostToDevice, cm->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(cm->stream);   // `items` dies with this scope
+        if (e != hipSuccess) return e;
+        cm->sv_items = (int)items.size();
+        cm->sv_d = d;
+    }
+    const size_t item_bytes = ((size_t)cm->sv_items * sizeof(int2) + 255) & ~(size_t)255;
+    double *rowpart = (double *)((char *)cm->sv_buf + item_bytes);
+    double *colpart = rowpart + nseg * d;
+    hipError_t e = bb::launch(symv_upper_kernel, dim3((unsigned)cm->sv_items), dim3(256), 0, cm->stream,
+                              (const double *)cm->m, d, dx, (const int2 *)cm->sv_buf, rowpart, colpart);
+    if (e == hipSuccess)
+        e = bb::launch(symv_reduce_kernel, dim3((unsigned)((d + 127) / 128)), dim3(1024), 0, cm->stream,
+                       (const double *)rowpart, (const double *)colpart, d, (int)nseg, dy);
+    return e;
+}
+
+// One Lanczos step's scalars, on the device (no host round trip inside a cycle):
+//   mode 0  alpha[k] = dc[k]                   after the first Gram-Schmidt pass
+//   mode 1  alpha[k] += dc[k]                  after the second
+//   mode 2  beta[k] = sqrt(dc[0]); inv[0] = 1 / beta[k], or 0 when the new direction has
+//           vanished against |alpha_k| + beta_{k-1} (an invariant subspace: every later
+//           basis vector of the cycle is then 0 and drops out of the tridiagonal matrix)
+__global__ void lanczos_scalars_kernel(const double *__restrict__ dc, int k, int mode,
+                                       double *__restrict__ alpha, double *__restrict__ beta,
+                                       double *__restrict__ inv) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (mode == 0) {
+        alpha[k] = dc[k];
+    } else if (mode == 1) {
+        alpha[k] += dc[k];
+    } else {
+        const double b2 = dc[0];
+        const double b = sqrt(b2 > 0.0 ? b2 : 0.0);
+        const double ref = fabs(alpha[k]) + (k > 0 ? beta[k - 1] : 0.0);
+        const bool alive = b > 1e-14 * (ref > 0.0 ? ref : 1.0);
+        beta[k] = alive ? b : 0.0;
+        inv[0] = alive ? 1.0 / b : 0.0;
+    }
+}
+
+// out = scale[0] * in, the scale read on the device
+__global__ __launch_bounds__(256) void scale_by_kernel(const double *__restrict__ in,
+                                                       const double *__restrict__ scale,
+                                                       double *__restrict__ out, int64_t d) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < d) out[i] = scale[0] * in[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -581,6 +860,8 @@ int bb_cm_destroy(bb_cm *cm) {
     (void)hipSetDevice(cm->device);
     bb::release_stream(cm->device, cm->stream);     // synchronises it
     (void)hipFree(cm->m);
+    (void)hipFree(cm->sv_buf);
+    (void)hipFree(cm->corr_buf);
     delete cm;
     (void)hipGetLastError();   // tear-down is best effort; its errors end here
     return BB_OK;
@@ -688,7 +969,23 @@ int bb_cm_normalize(bb_cm *cm, int64_t n_bins, const double *KRnorm, const doubl
         if (e == hipSuccess)
             e = hipMemcpyAsync(ke.p, KRexpected, (size_t)n_bins * sizeof(double), hipMemcpyHostToDevice, st);
     }
-    if (e == hipSuccess) {
+    const char *env = getenv("BB_CM_NORMALIZE_TILE");
+    const bool big = !(env && atoi(env) == 32) && d >= 2 * kNT;   // small maps: more, smaller tiles
+    if (e == hipSuccess && big) {
+        const uint64_t nt = (uint64_t)((d + kNT - 1) / kNT), pairs = nt * (nt + 1) / 2;
+        static bool attr_done = false;
+        if (!attr_done) {
+            e = hipFuncSetAttribute((const void *)normalize128_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kNormLds);
+            attr_done = e == hipSuccess;
+        }
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cm->device);
+        if (e == hipSuccess)
+            e = bb::launch(normalize128_kernel, dim3((unsigned)std::min<uint64_t>(pairs, (uint64_t)cus)),
+                           dim3(1024), (size_t)kNormLds, st, cm->m, d, n_bins, (const double *)kr.p,
+                           (const double *)ke.p, (unsigned)pairs);
+    } else if (e == hipSuccess) {
         const uint64_t nt = (uint64_t)((d + kT - 1) / kT);
         if (nt * (nt + 1) / 2 > 0x7fffffffull)
             return bb::fail(BB_ERR_INVALID, "bb_cm_normalize: matrix too large for one launch");
@@ -783,9 +1080,12 @@ int bb_cm_symv(bb_cm *cm, const double *x, double *y) {
     if (e == hipSuccess) e = dy.alloc((size_t)d * 8);
     if (e != hipSuccess) return bb::fail(BB_ERR_NOMEM, std::string("bb_cm_symv: ") + hipGetErrorString(e));
     e = hipMemcpyAsync(dx.p, x, (size_t)d * 8, hipMemcpyHostToDevice, cm->stream);
-    if (e == hipSuccess)
+    const char *env = getenv("BB_CM_SYMV_FULL");          // 1: read both triangles (round 2)
+    if (e == hipSuccess && env && atoi(env) != 0)
         e = bb::launch(symv_kernel, dim3((unsigned)((d + 4 * kSymvRows - 1) / (4 * kSymvRows))), dim3(256), 0, cm->stream,
                        (const double *)cm->m, d, (const double *)dx.p, (double *)dy.p);
+    else if (e == hipSuccess)
+        e = symv_enqueue(cm, (const double *)dx.p, (double *)dy.p);
     if (e == hipSuccess) e = hipStreamSynchronize(cm->stream);
     if (e == hipSuccess) e = hipMemcpy(y, dy.p, (size_t)d * 8, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return bb::fail(BB_ERR_HIP, std::string("bb_cm_symv: ") + hipGetErrorString(e));
@@ -795,9 +1095,11 @@ int bb_cm_symv(bb_cm *cm, const double *x, double *y) {
 // Restarted Lanczos with full re-orthogonalisation for the eigenpair of largest
 // magnitude -- the pair scipy.sparse.linalg.eigsh(matrix, k=1) returns (ARPACK's
 // default which='LM'), reference blueberry/datatypes.pyx:234.  Every matrix-vector
-// product is one sweep of the resident matrix (symv_kernel); the basis (<= kBasis
-// vectors of d doubles) stays on the device; only the scalars of the tridiagonal matrix
-// cross PCIe.  The sign of the vector is fixed: its largest-magnitude component is > 0.
+// product is one sweep of the UPPER TRIANGLE of the resident matrix (symv_upper_kernel; the
+// matrix is taken to be symmetric, as eigsh takes it); the basis (<= kBasis vectors of d
+// doubles) stays on the device and a whole cycle of up to kBasis steps is enqueued
+// without a host round trip; only the scalars of the tridiagonal matrix cross PCIe, once
+// per cycle.  The sign of the vector is fixed: its largest-magnitude component is > 0.
 int bb_cm_eigenvector(bb_cm *cm, double *vec, double *eigenvalue, double tol, int64_t max_matvecs,
                       int64_t *matvecs_used, double *residual) {
     BB_TRY(cm_check(cm, "bb_cm_eigenvector"));
@@ -832,51 +1134,62 @@ int bb_cm_eigenvector(bb_cm *cm, double *vec, double *eigenvalue, double tol, in
     e = hipMemcpy(dV, host.data(), (size_t)d * 8, hipMemcpyHostToDevice);
     int64_t used = 0;
     double theta = 0.0, resid = 0.0;
-    std::vector<double> alpha, beta, T, Z, c((size_t)m + 1);
+    std::vector<double> alpha, beta, T, Z;
+    // alpha[m] | beta[m] | 1 / beta of the current step: written by lanczos_scalars_kernel,
+    // read back once per cycle -- a cycle of up to 48 steps is enqueued without a host
+    // round trip (round 2 synchronised three times per step: 13 of the 56 ms of a call at
+    // d = 24,927)
+    bb::DevBuf sc;
+    if (e == hipSuccess) e = sc.alloc((size_t)(2 * m + 1) * 8);
+    double *d_alpha = (double *)sc.p, *d_beta = d_alpha + m, *d_inv = d_beta + m;
+    const char *env_full = getenv("BB_CM_SYMV_FULL");
+    const bool full = env_full && atoi(env_full) != 0;
     bool done = false;
     while (e == hipSuccess && !done) {
-        alpha.clear();
-        beta.clear();
-        int k = 0;
-        for (; k < m && e == hipSuccess; ++k) {
+        const int steps = (int)std::min<int64_t>(m, std::max<int64_t>(1, max_matvecs - used));
+        e = hipMemsetAsync(sc.p, 0, (size_t)(2 * m + 1) * 8, st);
+        for (int k = 0; k < steps && e == hipSuccess; ++k) {
             // w = M v_k
-            e = bb::launch(symv_kernel, dim3((unsigned)((d + 4 * kSymvRows - 1) / (4 * kSymvRows))), b256, 0, st,
-                           (const double *)cm->m, d, (const double *)(dV + (int64_t)k * d), dw);
+            if (full)
+                e = bb::launch(symv_kernel, dim3((unsigned)((d + 4 * kSymvRows - 1) / (4 * kSymvRows))), b256, 0, st,
+                               (const double *)cm->m, d, (const double *)(dV + (int64_t)k * d), dw);
+            else
+                e = symv_enqueue(cm, (const double *)(dV + (int64_t)k * d), dw);
             ++used;
             // coefficients against the whole basis (alpha_k is the last one), subtract, and
             // once more for the rounding the first pass leaves (classical Gram-Schmidt x 2)
-            double a_k = 0.0;
             for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
                 e = bb::launch(basis_dots_kernel, dim3((unsigned)(k + 1)), b256, 0, st,
                                (const double *)dV, d, (const double *)dw, dc);
                 if (e == hipSuccess)
                     e = bb::launch(basis_subtract_kernel, gvec, b256, 0, st, (const double *)dV, d,
                                    k + 1, (const double *)dc, dw);
-                if (e == hipSuccess) e = hipStreamSynchronize(st);
                 if (e == hipSuccess)
-                    e = hipMemcpy(c.data(), dc, (size_t)(k + 1) * 8, hipMemcpyDeviceToHost);
-                a_k += c[(size_t)k];
+                    e = bb::launch(lanczos_scalars_kernel, dim3(1), dim3(64), 0, st, (const double *)dc,
+                                   k, pass, d_alpha, d_beta, d_inv);
             }
-            if (e != hipSuccess) break;
-            alpha.push_back(a_k);
-            // beta_k = |w|
-            e = bb::launch(basis_dots_kernel, dim3(1), b256, 0, st, (const double *)dw, d,
-                           (const double *)dw, dc);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            double b2 = 0.0;
-            if (e == hipSuccess) e = hipMemcpy(&b2, dc, 8, hipMemcpyDeviceToHost);
-            const double b = sqrt(b2 > 0.0 ? b2 : 0.0);
-            beta.push_back(b);
-            const double scale_ref = fabs(a_k) + (k > 0 ? beta[(size_t)k - 1] : 0.0);
-            if (!(b > 1e-14 * (scale_ref > 0.0 ? scale_ref : 1.0)) || used >= max_matvecs) {
-                ++k;                       // invariant subspace reached (or out of budget)
-                break;
-            }
+            // beta_k = |w|, v_{k+1} = w / beta_k (0 once the direction has vanished)
+            if (e == hipSuccess)
+                e = bb::launch(basis_dots_kernel, dim3(1), b256, 0, st, (const double *)dw, d,
+                               (const double *)dw, dc);
+            if (e == hipSuccess)
+                e = bb::launch(lanczos_scalars_kernel, dim3(1), dim3(64), 0, st, (const double *)dc, k,
+                               2, d_alpha, d_beta, d_inv);
             if (k + 1 <= m && e == hipSuccess)
-                e = bb::launch(scale_kernel, gvec, b256, 0, st, (const double *)dw, 1.0 / b,
-                               dV + (int64_t)(k + 1) * d, d);
+                e = bb::launch(scale_by_kernel, gvec, b256, 0, st, (const double *)dw,
+                               (const double *)d_inv, dV + (int64_t)(k + 1) * d, d);
         }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        std::vector<double> ab((size_t)2 * m);
+        if (e == hipSuccess) e = hipMemcpy(ab.data(), sc.p, (size_t)2 * m * 8, hipMemcpyDeviceToHost);
         if (e != hipSuccess) break;
+        // the cycle ends where the new direction vanished (an invariant subspace), else at `steps`
+        int n_steps = steps;
+        for (int k = 0; k < steps; ++k)
+            if (ab[(size_t)m + k] == 0.0) { n_steps = k + 1; break; }
+        used -= steps - n_steps;               // products of vanished directions do not count
+        alpha.assign(ab.begin(), ab.begin() + n_steps);
+        beta.assign(ab.begin() + m, ab.begin() + m + n_steps);
         const int n = (int)alpha.size();
         T.assign((size_t)n * n, 0.0);
         for (int i = 0; i < n; ++i) {
@@ -927,12 +1240,27 @@ int bb_cm_correlation(bb_cm *cm, double *tflops) {
     BB_TRY(cm_check(cm, "bb_cm_correlation"));
     const int64_t d = cm->d;
     const int64_t dp = bb::round_up(d, kGT), ldx = bb::round_up(d, kGK);
-    bb::DevBuf xc, g, sd;
-    hipError_t e = xc.alloc((size_t)dp * ldx * 8);
-    if (e == hipSuccess) e = g.alloc((size_t)dp * dp * 8);
-    if (e == hipSuccess) e = sd.alloc((size_t)d * 8);
+    // centred rows | Gram matrix | standard deviations: ONE grow-only allocation kept with
+    // the handle.  Round 2 allocated the two matrix-sized temporaries per call, and on this
+    // platform the first touch of a fresh block of that size costs 0.17-0.35 s
+    // (tools/alloc_probe.py): the whole call took 1.5x its Gram kernel.
+    struct View { void *p; } xc, g, sd;
+    const size_t xc_bytes = ((size_t)dp * ldx * 8 + 255) & ~(size_t)255;
+    const size_t g_bytes = ((size_t)dp * dp * 8 + 255) & ~(size_t)255;
+    const size_t need = xc_bytes + g_bytes + (size_t)d * 8;
+    hipError_t e = hipSuccess;
+    if (need > cm->corr_bytes) {
+        (void)hipFree(cm->corr_buf);
+        cm->corr_buf = nullptr;
+        cm->corr_bytes = 0;
+        e = hipMalloc(&cm->corr_buf, need);
+        if (e == hipSuccess) cm->corr_bytes = need;
+    }
     if (e != hipSuccess)
         return bb::fail(BB_ERR_NOMEM, std::string("bb_cm_correlation: ") + hipGetErrorString(e));
+    xc.p = cm->corr_buf;
+    g.p = (char *)cm->corr_buf + xc_bytes;
+    sd.p = (char *)cm->corr_buf + xc_bytes + g_bytes;
     hipStream_t st = cm->stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const double fact_inv = 1.0 / (double)(d - 1);   // numpy: true_divide(1, N - ddof); d = 1 -> inf

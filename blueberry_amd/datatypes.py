@@ -470,7 +470,7 @@ class ContactMap(object):
                                               int(max_matvecs), used, res), "bb_cm_eigenvector")
         self.eigenvalue_, self.eigen_matvecs_, self.eigen_residual_ = (
             float(lam.value), int(used.value), float(res.value))
-        if self.eigen_residual_ > float(tol) * abs(self.eigenvalue_) and self.eigen_matvecs_ >= max_matvecs:
+        if self.eigen_residual_ > max(float(tol), 2.3e-16) * abs(self.eigenvalue_):
             # scipy's eigsh raises ArpackNoConvergence here; the unconverged pair travels
             # with the exception as ARPACK's does
             raise EigenNoConvergence(

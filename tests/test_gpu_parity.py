@@ -1438,12 +1438,13 @@ def test_eigenvector_reports_no_convergence():
     rng = numpy.random.default_rng(3)
     q, _ = numpy.linalg.qr(rng.standard_normal((d, d)))
     lam = numpy.linspace(0.0, 1.0, d)
-    lam[-1], lam[-2] = 2.0, 2.0 - 1e-9
+    lam[-10:] = 2.0 - 1e-6 * numpy.arange(10)[::-1]      # ten eigenvalues within 5e-6 of the top
     m = (q * lam) @ q.T
     m = 0.5 * (m + m.T)
     cm = bb.ContactMap.from_matrix(m)
     with pytest.raises(bb.EigenNoConvergence) as err:
-        cm.eigenvector(tol=1e-13, max_matvecs=48)
-    assert abs(err.value.eigenvalue - 2.0) < 1e-6 and err.value.eigenvector.shape == (d,)
-    v = cm.eigenvector(tol=1e-7)                      # a reachable tolerance converges
-    assert abs(cm.eigenvalue_ - 2.0) < 1e-8 and abs(numpy.linalg.norm(v) - 1) < 1e-12
+        cm.eigenvector(tol=1e-14, max_matvecs=48)
+    assert cm.eigen_residual_ > 1e-14 * 2.0 and cm.eigen_matvecs_ >= 48
+    assert abs(err.value.eigenvalue - 2.0) < 1e-4 and err.value.eigenvector.shape == (d,)
+    v = cm.eigenvector(tol=1e-4)                      # a reachable tolerance converges
+    assert abs(cm.eigenvalue_ - 2.0) < 1e-4 and abs(numpy.linalg.norm(v) - 1) < 1e-12

@@ -68,14 +68,32 @@ for n_bins in [int(a) for a in sys.argv[1:]] or [24926]:
           % (t * 1e3, pairs * 12 / t / 1e9))
     eng.close()
     # eigenvector (Lanczos over the resident matrix) and correlation (fp64 MFMA Gram kernel)
-    t0 = time.perf_counter(); v = cm.eigenvector(); t = time.perf_counter() - t0
-    print("eigenvector: %d matrix-vector products, residual %.1e    %.1f ms  -> %.0f GB/s over the products (8 B per element each)"
-          % (cm.eigen_matvecs_, cm.eigen_residual_, t * 1e3, cm.eigen_matvecs_ * d * d * 8 / t / 1e9))
+    cm.eigenvector(max_matvecs=2)                                # the product's scratch is made once per handle
+    for label, env in (("upper triangle, one pass serves both ends", None), ("both triangles (round 2)", "1")):
+        if env:
+            os.environ["BB_CM_SYMV_FULL"] = env
+        t0 = time.perf_counter(); v = cm.eigenvector(); t = time.perf_counter() - t0
+        os.environ.pop("BB_CM_SYMV_FULL", None)
+        print("eigenvector [%s]: %d matrix-vector products, residual %.1e    %.1f ms  -> %.0f GB/s over the products (8 B per PAIR each: %.1f %% of 8 TB/s)"
+              % (label, cm.eigen_matvecs_, cm.eigen_residual_, t * 1e3, cm.eigen_matvecs_ * pairs * 8 / t / 1e9,
+                 cm.eigen_matvecs_ * pairs * 8 / t / 8e12 * 100))
+    x = numpy.random.default_rng(2).standard_normal(d); y = numpy.empty(d)
+    for label, env in (("upper triangle", None), ("both triangles", "1")):
+        if env:
+            os.environ["BB_CM_SYMV_FULL"] = env
+        t, _ = timed(lambda: _lib.check(cm._resident()._lib.bb_cm_symv(cm._resident()._h, _lib.as_f64_ptr(x), _lib.as_f64_ptr(y)), "symv"), 5)
+        os.environ.pop("BB_CM_SYMV_FULL", None)
+        print("  one product through bb_cm_symv [%s] (H2D + product + D2H of d doubles)  %.3f ms" % (label, t * 1e3))
     cc = bb.ContactMap.from_matrix(numpy.zeros((1, 1)))      # a copy to turn into its correlation
     cc._host, cc._dev, cc.n_bins = None, type(cm._resident()).from_host(cm.to_host(), 0), n_bins
-    t0 = time.perf_counter(); cc.correlation(); t = time.perf_counter() - t0
-    print("correlation: Gram kernel %.1f TFLOP/s fp64 (%.0f %% of the 78.6 TFLOP/s matrix peak), whole call %.1f ms"
-          % (cc.correlation_tflops_, cc.correlation_tflops_ / 78.6 * 100, t * 1e3))
+    nt = (d + 127) // 128; pairs_t = nt * (nt + 1) // 2; ldx = (d + 15) // 16 * 16
+    for tag in ("first call of the handle (allocates its scratch)", "second call"):
+        if tag.startswith("second"):
+            _lib.check(cc._dev._lib.bb_cm_upload(cc._dev._h, _lib.as_f64_ptr(cm.to_host()), d), "upload")
+        t0 = time.perf_counter(); cc.correlation(); t = time.perf_counter() - t0
+        gram_ms = pairs_t * 2.0 * 128 * 128 * ldx / (cc.correlation_tflops_ * 1e12) * 1e3
+        print("correlation, %s: Gram kernel %.1f TFLOP/s fp64 (%.0f %% of the 78.6 TFLOP/s matrix peak, %.1f ms), whole call %.1f ms = %.2f x the kernel"
+              % (tag, cc.correlation_tflops_, cc.correlation_tflops_ / 78.6 * 100, gram_ms, t * 1e3, t * 1e3 / gram_ms))
     del cc
     thr = float(numpy.median(cm.marginals()))
     t0 = time.perf_counter(); cm.filter(thr); t = time.perf_counter() - t0
