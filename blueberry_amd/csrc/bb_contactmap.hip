@@ -52,6 +52,17 @@ __device__ __forceinline__ double nan_to_num(double v) {
     return v;
 }
 
+// A workgroup barrier that orders LDS only.  __syncthreads() is also a release of the
+// wave's GLOBAL stores: s_waitcnt vmcnt(0) in front of every s_barrier, i.e. the write
+// acknowledgements of a whole tile (and the next tile's loads) twice per tile.  The tile
+// pair belongs to this workgroup alone and no thread reads a global cell another thread
+// of the launch writes, so nothing global needs ordering here.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // One workgroup per tile pair (TJ <= TK) of the (d,d) matrix, IN PLACE: computes the
 // upper tile, writes it back, and writes its mirror through LDS so that every global
 // access is row-contiguous.  A workgroup owns its tile pair alone, and the barrier
@@ -121,6 +132,11 @@ __global__ __launch_bounds__(kT * 8) void normalize_kernel(double *m, int64_t d,
 // loads of its next pair are in flight while the mirror of the current one goes out
 // (one workgroup per CU has nobody else to cover its load latency).  Same arithmetic,
 // same order, same bits as normalize_kernel.  Dynamic LDS: tile[128][129] doubles.
+#ifdef BB_CM_PLAIN_STORES
+__device__ __forceinline__ void nt_store(double *p, double v) { *p = v; }
+#else
+__device__ __forceinline__ void nt_store(double *p, double v) { __builtin_nontemporal_store(v, p); }
+#endif
 constexpr int kNT = 128;                  // tile edge
 constexpr int kNQ = kNT / 8;              // rows per thread: 1024 threads = 128 columns x 8
 constexpr int kNormLds = kNT * (kNT + 1) * 8;
@@ -156,10 +172,10 @@ __global__ __launch_bounds__(1024) void normalize128_kernel(double *m, int64_t d
             const bool scaled = j < n_bins && k < n_bins && j <= k;
             v[q] = nv[q];
             if (scaled) v[q] = v[q] / (kr[j] * krk * krexp[k - j]);
-            if (j < d && k < d && (j <= k || TJ != TK)) m[j * d + k] = nan_to_num(v[q]);
+            if (j < d && k < d && (j <= k || TJ != TK)) nt_store(m + j * d + k, nan_to_num(v[q]));
             ntile[rr * (kNT + 1) + tx] = v[q];
         }
-        __syncthreads();
+        lds_barrier();
         const unsigned bn = b + gridDim.x;
         if (bn < n_pairs) fetch(bn);          // in flight while the mirror goes out
 #pragma unroll
@@ -172,10 +188,10 @@ __global__ __launch_bounds__(1024) void normalize128_kernel(double *m, int64_t d
                 // own value (nobody has written it: phase 1 leaves the lower cells alone)
                 const double w = (kk < n_bins && jj < n_bins) ? ntile[tx * (kNT + 1) + rr]
                                                               : m[kk * d + jj];
-                m[kk * d + jj] = nan_to_num(w);
+                nt_store(m + kk * d + jj, nan_to_num(w));
             }
         }
-        __syncthreads();                      // the tile is free again
+        lds_barrier();                        // the tile is free again
         b = bn;
     }
 }
@@ -438,14 +454,14 @@ __global__ __launch_bounds__(256, 2) void symv_upper_kernel(const double *__rest
         }
 #pragma unroll
         for (int g = 0; g < kSvGroup; ++g) meet[wave][g][lane] = cacc[g];
-        __syncthreads();
+        lds_barrier();   // (LDS only: nobody reads the global cells stored here)
         for (int j = threadIdx.x; j < 64 * kSvGroup; j += 256) {
             const int g = j >> 6, l = j & 63;
             const int64_t c = cg + j;
             if (c < c_end)
                 colpart[I * d + c] = ((meet[0][g][l] + meet[1][g][l]) + meet[2][g][l]) + meet[3][g][l];
         }
-        __syncthreads();
+        lds_barrier();   // (LDS only: nobody reads the global cells stored here)
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {

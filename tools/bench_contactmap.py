@@ -68,7 +68,11 @@ for n_bins in [int(a) for a in sys.argv[1:]] or [24926]:
           % (t * 1e3, pairs * 12 / t / 1e9))
     eng.close()
     # eigenvector (Lanczos over the resident matrix) and correlation (fp64 MFMA Gram kernel)
-    cm.eigenvector(max_matvecs=2)                                # the product's scratch is made once per handle
+    try:
+        cm.eigenvector(max_matvecs=2)
+    except bb.EigenNoConvergence:
+        pass
+    #                             # the product's scratch is made once per handle
     for label, env in (("upper triangle, one pass serves both ends", None), ("both triangles (round 2)", "1")):
         if env:
             os.environ["BB_CM_SYMV_FULL"] = env
