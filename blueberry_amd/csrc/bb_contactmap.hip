@@ -523,6 +523,29 @@ __global__ __launch_bounds__(256) void basis_dots_kernel(const double *__restric
     if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
 
+// The same in two stages for long vectors: segment s of kDotSegs of vector j -> part[j *
+// kDotSegs + s]; lanczos_finish_kernel adds a vector's segments in order.  One workgroup
+// per vector walked d = 25k doubles in 19-30 us on 1 to 48 CUs, three times per Lanczos
+// step: more than a tenth of the step.
+constexpr int kDotSegs = 16;
+__global__ __launch_bounds__(256) void basis_dots_part_kernel(const double *__restrict__ V, int64_t d,
+                                                              const double *__restrict__ w,
+                                                              double *__restrict__ part) {
+    __shared__ double sh[256];
+    const double *v = V + (int64_t)blockIdx.x * d;
+    const int64_t per = (d + kDotSegs - 1) / kDotSegs;
+    const int64_t i0 = (int64_t)blockIdx.y * per, i1 = std::min<int64_t>(d, i0 + per);
+    double a = 0.0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) a = fma(v[i], w[i], a);
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.x * kDotSegs + blockIdx.y] = sh[0];
+}
+
 // w -= sum_{j<k} c[j] V[j]
 __global__ __launch_bounds__(256) void basis_subtract_kernel(const double *__restrict__ V, int64_t d,
                                                              int k, const double *__restrict__ c,
@@ -818,9 +841,19 @@ hipError_t symv_enqueue(bb_cm *cm, const double *dx, double *dy) {
 //   mode 2  beta[k] = sqrt(dc[0]); inv[0] = 1 / beta[k], or 0 when the new direction has
 //           vanished against |alpha_k| + beta_{k-1} (an invariant subspace: every later
 //           basis vector of the cycle is then 0 and drops out of the tridiagonal matrix)
-__global__ void lanczos_scalars_kernel(const double *__restrict__ dc, int k, int mode,
+//   part != NULL: first dc[j] = the sum of vector j's kDotSegs segment dots, j < n_vec
+__global__ void lanczos_scalars_kernel(double *__restrict__ dc, int k, int mode,
                                        double *__restrict__ alpha, double *__restrict__ beta,
-                                       double *__restrict__ inv) {
+                                       double *__restrict__ inv, const double *__restrict__ part,
+                                       int n_vec) {
+    if (part != nullptr) {
+        if ((int)threadIdx.x < n_vec) {
+            double t = 0.0;
+            for (int q = 0; q < kDotSegs; ++q) t += part[(int)threadIdx.x * kDotSegs + q];
+            dc[threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (mode == 0) {
         alpha[k] = dc[k];
@@ -1156,8 +1189,9 @@ int bb_cm_eigenvector(bb_cm *cm, double *vec, double *eigenvalue, double tol, in
     // round trip (round 2 synchronised three times per step: 13 of the 56 ms of a call at
     // d = 24,927)
     bb::DevBuf sc;
-    if (e == hipSuccess) e = sc.alloc((size_t)(2 * m + 1) * 8);
-    double *d_alpha = (double *)sc.p, *d_beta = d_alpha + m, *d_inv = d_beta + m;
+    if (e == hipSuccess) e = sc.alloc((size_t)(2 * m + 1 + (m + 1) * kDotSegs) * 8);
+    double *d_alpha = (double *)sc.p, *d_beta = d_alpha + m, *d_inv = d_beta + m, *d_part = d_inv + 1;
+    const bool two_stage = d >= 4096;
     const char *env_full = getenv("BB_CM_SYMV_FULL");
     const bool full = env_full && atoi(env_full) != 0;
     bool done = false;
@@ -1175,22 +1209,33 @@ int bb_cm_eigenvector(bb_cm *cm, double *vec, double *eigenvalue, double tol, in
             // coefficients against the whole basis (alpha_k is the last one), subtract, and
             // once more for the rounding the first pass leaves (classical Gram-Schmidt x 2)
             for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
-                e = bb::launch(basis_dots_kernel, dim3((unsigned)(k + 1)), b256, 0, st,
-                               (const double *)dV, d, (const double *)dw, dc);
+                // the dots (in two stages for long vectors) and alpha_k, THEN the subtraction
+                // (which overwrites w; dc is not written again before it has been read)
+                if (two_stage)
+                    e = bb::launch(basis_dots_part_kernel, dim3((unsigned)(k + 1), kDotSegs), b256, 0, st,
+                                   (const double *)dV, d, (const double *)dw, d_part);
+                else
+                    e = bb::launch(basis_dots_kernel, dim3((unsigned)(k + 1)), b256, 0, st,
+                                   (const double *)dV, d, (const double *)dw, dc);
+                if (e == hipSuccess)
+                    e = bb::launch(lanczos_scalars_kernel, dim3(1), dim3(64), 0, st, dc, k, pass, d_alpha,
+                                   d_beta, d_inv, (const double *)(two_stage ? d_part : nullptr), k + 1);
                 if (e == hipSuccess)
                     e = bb::launch(basis_subtract_kernel, gvec, b256, 0, st, (const double *)dV, d,
                                    k + 1, (const double *)dc, dw);
-                if (e == hipSuccess)
-                    e = bb::launch(lanczos_scalars_kernel, dim3(1), dim3(64), 0, st, (const double *)dc,
-                                   k, pass, d_alpha, d_beta, d_inv);
             }
             // beta_k = |w|, v_{k+1} = w / beta_k (0 once the direction has vanished)
+            if (e == hipSuccess) {
+                if (two_stage)
+                    e = bb::launch(basis_dots_part_kernel, dim3(1, kDotSegs), b256, 0, st,
+                                   (const double *)dw, d, (const double *)dw, d_part);
+                else
+                    e = bb::launch(basis_dots_kernel, dim3(1), b256, 0, st, (const double *)dw, d,
+                                   (const double *)dw, dc);
+            }
             if (e == hipSuccess)
-                e = bb::launch(basis_dots_kernel, dim3(1), b256, 0, st, (const double *)dw, d,
-                               (const double *)dw, dc);
-            if (e == hipSuccess)
-                e = bb::launch(lanczos_scalars_kernel, dim3(1), dim3(64), 0, st, (const double *)dc, k,
-                               2, d_alpha, d_beta, d_inv);
+                e = bb::launch(lanczos_scalars_kernel, dim3(1), dim3(64), 0, st, dc, k, 2, d_alpha,
+                               d_beta, d_inv, (const double *)(two_stage ? d_part : nullptr), 1);
             if (k + 1 <= m && e == hipSuccess)
                 e = bb::launch(scale_by_kernel, gvec, b256, 0, st, (const double *)dw,
                                (const double *)d_inv, dV + (int64_t)(k + 1) * d, d);

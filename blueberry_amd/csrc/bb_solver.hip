@@ -1351,9 +1351,12 @@ int bb_solver_peer_connect(bb_solver *s, const void *handles) {
     }
     BB_TRY(s->dtype == BB_F32 ? build_peer_tables<float>(s) : build_peer_tables<double>(s));
     BB_TRY(dev_alloc(&s->d_peer_state, 1));
-    BB_TRY(dev_alloc(&s->d_peer_counter, 1));
+    // the top counter + one per block on a line of its own (reduce_sliced_kernel's two-level
+    // check-in), also good for reduce_kernel, which uses the top one only
+    const int64_t n_counters = 32 * (s->L.n_blocks + 1);
+    BB_TRY(dev_alloc(&s->d_peer_counter, n_counters));
     BB_HIP_CHECK(hipMemset(s->d_peer_state, 0, sizeof(PeerState)));
-    BB_HIP_CHECK(hipMemset(s->d_peer_counter, 0, sizeof(unsigned)));
+    BB_HIP_CHECK(hipMemset(s->d_peer_counter, 0, (size_t)n_counters * sizeof(unsigned)));
     // ticks of wall_clock64(): ask the runtime, fall back to gfx9's 100 MHz.  The query
     // is allowed to fail (older runtimes); its error is consumed here, on the spot.
     int khz = 0;

@@ -1306,12 +1306,27 @@ __global__ __launch_bounds__(128 * S) void reduce_sliced_kernel(ReduceParams<T> 
         }
     }
     if (p.mode == kReducePeer && peer_live) {
-        // as in reduce_kernel: every workgroup makes its stores visible system-wide and
-        // checks in; the last one raises this rank's flag on every peer (release)
+        // Every workgroup makes its stores visible system-wide and checks in; the last one
+        // raises this rank's flag on every peer (release).  ONE lane fences for the
+        // workgroup, behind a barrier that every storing wave reaches with its stores
+        // acknowledged (__syncthreads() waits vmcnt(0)): a release is a write-back of the
+        // XCD's L2, and with all 16 waves of the workgroup issuing one the push cost 33 us
+        // instead of 12 (tools/exchange_timing.py; reduce_kernel's workgroups have 2 waves).
         __shared__ int last;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope
         __syncthreads();
-        if (tid == 0) last = atomicAdd(p.peer_counter, 1u) == gridDim.x * gridDim.y - 1;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler may drop its own)
+            // two levels: the gridDim.y workgroups of a block check in on the block's own
+            // counter (its own 128-byte line), the last of them on the top counter -- 12 + 35
+            // adds in a row instead of 420 on one word (11-13 ns each) at a 1/8 share of N=50k
+            unsigned *mine = p.peer_counter + 32 * (b + 1);
+            last = 0;
+            if (atomicAdd(mine, 1u) == gridDim.y - 1) {
+                atomicExch(mine, 0u);
+                last = atomicAdd(p.peer_counter, 1u) == gridDim.x - 1;
+            }
+        }
         __syncthreads();
         if (last) {
             if (tid == 0) atomicExch(p.peer_counter, 0u);

@@ -15,10 +15,12 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     n = r["Name"]
-    if any(k in n for k in ("normalize", "symv", "column_sums", "gram_kernel", "center_rows", "corr_finalize",
-                            "scatter_", "gather_kernel", "pack_units", "basis_")):
-        print("  %-48s calls %5s  avg %10.2f us  min %10.2f  max %10.2f" % (
-            n.split("(")[0][-48:], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+    import re
+    hit = re.search(r"(normalize\w*|symv\w*|column_sums\w*|gram_\w+|center_rows\w*|corr_finalize\w*|scatter_\w+|"
+                    r"gather_kernel|pack_units\w*|basis_\w+|lanczos_\w+|scale_\w*kernel|keep_scan\w*)", n)
+    if hit:
+        print("  %-32s calls %5s  avg %10.2f us  min %10.2f  max %10.2f" % (
+            hit.group(1), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 PY
 done
 cat $out
