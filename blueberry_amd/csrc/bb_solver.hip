@@ -63,6 +63,8 @@ struct bb_solver {
     int n_waves = 0, n_slots = 0;
     int wpb = 4;                   // waves per workgroup of the sweep: 4, or 8 (paired, see kernel)
     int wg_map = 0;                // block index -> run of chunks (stress_grad_kernel): 0 identity
+    int dense_u0 = -1;             // dense tile list: this rank's first global unit (the kernel then
+                                   // computes a wave's first descriptor), else -1
     int defer_cap_units = 0;       // fp32: units of row sums a wave can park in LDS (0 = none)
     int64_t defer_lds_bytes = 0;   // dynamic LDS per workgroup for that, 0 = per-unit stores
     unsigned defer_attr_done = 0;  // kernel variants whose dynamic-LDS ceiling was raised
@@ -447,7 +449,7 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
         BB_HIP_CHECK(bb::launch(kern, grid, block, (size_t)(LDS), s->stream, units, X,          \
                                 s->d_udesc, s->chunk_q, s->chunk_r, s->d_wave_slots, rowpart,   \
                                 colpart, s->d_stresspart, s->defer_cap_units,                   \
-                                s->lds_wave_floats, s->wg_map));                                \
+                                s->lds_wave_floats, s->wg_map, s->dense_u0));                   \
     } while (0)
 #define BB_LAUNCH2(NTV, OPV, DEF, LDS)                                                          \
     do {                                                                                        \
@@ -763,6 +765,10 @@ int bb_solver_create(bb_solver **out, int64_t n_bins, int dtype, int device, int
         }
     }
     if (rc == BB_OK) rc = bb_layout_rank_units(s->L.n_units, rank, world, &s->u_begin, &s->u_end);
+    if (rc == BB_OK && tile_I == nullptr && s->u_end < ((int64_t)1 << 31)) {
+        const char *e = getenv("BB_ARITH_DESC");
+        if (!(e && atoi(e) == 0)) s->dense_u0 = (int)s->u_begin;
+    }
     if (rc == BB_OK) {
         hipError_t e = bb::acquire_stream(device, &s->stream);
         if (e != hipSuccess)

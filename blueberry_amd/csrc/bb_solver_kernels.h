@@ -683,7 +683,7 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
     const T *__restrict__ units, const T *__restrict__ X, const int2 *__restrict__ udesc,
     int chunk_q, int chunk_r, const int2 *__restrict__ wave_slots, T *__restrict__ rowpart,
     T *__restrict__ colpart, double *__restrict__ stresspart, int cap_units, int lds_wave_floats,
-    int wg_map) {
+    int wg_map, int dense_u0) {
     using Vec = typename Traits<T>::Vec;
     constexpr int VPL = Traits<T>::VPL;
     constexpr int VW = Lay<T, W>::VW;
@@ -752,7 +752,25 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
                 store_strip<T, W>(st.gc, colpart + (int64_t)sl * (3 * VW), lane);
         };
 
-        int2 dc = udesc[ua];                                   // current unit
+        // The wave's FIRST unit stands between the kernel's arguments and its first
+        // coordinate loads: a cold descriptor load there is one more dependent memory round
+        // trip (0.8 us of every launch).  A dense layout (dense_u0 >= 0: this rank's first
+        // global unit) has tile t = J (J + 1) / 2 + I in strip-major order (SPEC 3.1,
+        // bb_layout_dense_tiles), so that descriptor is arithmetic; the later ones come from
+        // the table as before, one unit ahead of their use.
+        int2 dc;
+        if (dense_u0 >= 0) {
+            constexpr int UPT = VW / Lay<T, W>::RPU;
+            const unsigned g = (unsigned)dense_u0 + (unsigned)ua;
+            const unsigned t = g / UPT, sub = g % UPT;
+            unsigned J = (unsigned)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+            while (J * (J + 1) / 2 > t) --J;
+            while ((J + 1) * (J + 2) / 2 <= t) ++J;
+            const unsigned I = t - J * (J + 1) / 2;
+            dc = make_int2((int)(I * VW + sub * Lay<T, W>::RPU), (int)(J * VW));
+        } else {
+            dc = udesc[ua];                                    // current unit
+        }
         int2 dn = udesc[ua + 1 < ub ? ua + 1 : ua];            // next unit
         // Prologue: the x rows of the first unit, then its 8 matrix rows.
         // Row coordinates of a unit, one unit ahead.  XRowS: 3*RPU wave-uniform scalars
@@ -1026,10 +1044,10 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
         }
     }
 
-    // per-wave stress (fixed shuffle tree)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) stress += __shfl_down(stress, off, 64);
-    if (lane == 0) stresspart[w] = stress;
+    // per-wave stress: fixed DPP tree, total in lane 63 (no LDS round trips at the very end
+    // of the launch: six __shfl_down steps of a double are twelve ds_bpermute)
+    stress = wave_sum_hi(stress);
+    if (lane == 63) stresspart[w] = stress;
     wave_stamp(stresspart, n_waves_all, w, 3);                        // partials issued
 }
 
