@@ -6,8 +6,8 @@
 # only, as MI355X_MICROARCH.md's HBM section prescribes).  Writes
 #   gpurun_out/pmc_<tag>_n<bins>.txt        per-dispatch averages + the kernel stats table
 #   gpurun_out/pmc_entry_<tag>_n<bins>.json the entry for profiles/pmc_latest.json
-tag=${1:-x}; bins=${2:-50000}; dtype=${3:-float32}
-R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/prof_${tag}_n$bins; export TMPDIR=/tmp
+tag=${1:-x}; bins=${2:-50000}; dtype=${3:-float32}; sfx=""; [ $dtype = float64 ] && sfx=_f64
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/prof_${tag}_n$bins$sfx; export TMPDIR=/tmp
 mkdir -p $O
 B="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --converge-steps 0 --reps 0 --bins $bins --dtype $dtype"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O.trace.log 2>&1 || exit 1
@@ -15,7 +15,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_IN
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $B > $O.fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $B > $O.write.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq2 -- $B > $O.sq2.log 2>&1 || exit 1
-python3 - > $R/gpurun_out/pmc_${tag}_n$bins.txt <<PY
+python3 - > $R/gpurun_out/pmc_${tag}_n$bins$sfx.txt <<PY
 import csv, glob, collections, json
 avg = {}
 for sub in ("sq","fetch","write","sq2"):
@@ -36,11 +36,11 @@ alg = n*(n-1)//2*es
 if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
     hbm = avg["FETCH_SIZE"][0]*1024*2 + avg["WRITE_SIZE"][0]*1024
     entry = {"bins": n, "dtype": "$dtype", "gpus": 1, "kernel": kname,
-             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python3 bench.py --steps 10 --warmup 2 --bins %d, averaged over the kernel's %d dispatches; profiles/r02_pmc_${tag}_n%d.txt" % (n, avg["FETCH_SIZE"][1], n),
+             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python3 bench.py --steps 10 --warmup 2 --bins %d --dtype $dtype, averaged over the kernel's %d dispatches; profiles/r03_pmc_${tag}_n%d$sfx.txt" % (n, avg["FETCH_SIZE"][1], n),
              "FETCH_SIZE_KB_avg": avg["FETCH_SIZE"][0], "WRITE_SIZE_KB_avg": avg["WRITE_SIZE"][0],
              "correction": "gfx950: FETCH_SIZE reports 1/2 of a wide coalesced read stream -> x2; WRITE_SIZE exact (MI355X_MICROARCH.md, HBM)",
              "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg,
              "traffic_over_algorithmic": hbm/alg}
-    json.dump(entry, open("$R/gpurun_out/pmc_entry_${tag}_n$bins.json","w"), indent=1)
+    json.dump(entry, open("$R/gpurun_out/pmc_entry_${tag}_n$bins$sfx.json","w"), indent=1)
     print("entry", json.dumps(entry))
 PY
