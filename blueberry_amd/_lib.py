@@ -85,6 +85,7 @@ SIGNATURES = {
     "bb_solver_set_timing": (c_int, [c_void_p, c_int]),
     "bb_solver_get_timing": (c_int, [c_void_p, p_dbl, p_dbl, p_i64]),
     "bb_solver_get_step_timing": (c_int, [c_void_p, p_dbl]),
+    "bb_solver_measure_event_gap": (c_int, [c_void_p, c_int, p_dbl]),
     "bb_solver_measure_stream_read": (c_int, [c_void_p, c_int, p_dbl]),
     "bb_solver_iteration_path": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "bb_solver_traffic": (c_int, [c_void_p, p_i64, p_i64]),

@@ -1644,6 +1644,36 @@ int bb_solver_get_step_timing(bb_solver *s, double *step_ms_avg) {
     return BB_OK;
 }
 
+int bb_solver_measure_event_gap(bb_solver *s, int pairs, double *ms_avg) {
+    BB_REQUIRE(s != nullptr && ms_avg != nullptr, "bb_solver_measure_event_gap: NULL argument");
+    BB_REQUIRE(pairs >= 1 && pairs <= 256, "bb_solver_measure_event_gap: bad pairs");
+    BB_TRY(check_ready(s, "bb_solver_measure_event_gap"));
+    BB_TRY(bb::enter_device(s->device));
+    std::vector<hipEvent_t> ev((size_t)2 * pairs, nullptr);
+    hipError_t e = hipSuccess;
+    for (auto &x : ev)
+        if (e == hipSuccess) e = hipEventCreate(&x);
+    for (int k = 0; k < pairs && e == hipSuccess; ++k) {
+        // behind a sweep launch, as the timed intervals are (the sweep only writes partials)
+        if (!s->row_owner && launch_grad(s) != BB_OK) e = hipErrorUnknown;
+        if (e == hipSuccess) e = hipEventRecord(ev[(size_t)2 * k], s->stream);
+        if (e == hipSuccess) e = hipEventRecord(ev[(size_t)2 * k + 1], s->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    double t = 0.0;
+    for (int k = 0; k < pairs && e == hipSuccess; ++k) {
+        float a = 0.f;
+        e = hipEventElapsedTime(&a, ev[(size_t)2 * k], ev[(size_t)2 * k + 1]);
+        t += a;
+    }
+    for (auto x : ev)
+        if (x) (void)hipEventDestroy(x);
+    if (e != hipSuccess)
+        return bb::fail(BB_ERR_HIP, std::string("bb_solver_measure_event_gap: ") + hipGetErrorString(e));
+    *ms_avg = t / pairs;
+    return BB_OK;
+}
+
 int bb_solver_measure_stream_read(bb_solver *s, int launches, double *ms_avg) {
     BB_REQUIRE(s != nullptr && ms_avg != nullptr, "bb_solver_measure_stream_read: NULL argument");
     BB_REQUIRE(launches >= 1 && launches <= 1000, "bb_solver_measure_stream_read: bad launches");

@@ -320,6 +320,14 @@ class HipEngine(object):
         return {"grad_ms": float(g.value), "reduce_ms": float(r.value), "launches": int(n.value),
                 "step_ms": float(st.value)}
 
+    def event_gap_ms(self, pairs=16):
+        """Average ms between two HIP events recorded back to back behind a sweep launch:
+        what an event-timed interval contains besides its kernel (measurement aid)."""
+        ms = _lib.c_dbl()
+        _lib.check(self._lib.bb_solver_measure_event_gap(self._h, int(pairs), ms),
+                   "bb_solver_measure_event_gap")
+        return float(ms.value)
+
     def stream_read_ms(self, launches=10):
         """Average ms of a read-only sweep over the resident units (measurement aid)."""
         ms = _lib.c_dbl()
