@@ -242,7 +242,9 @@ __device__ __forceinline__ void pair_step(const typename Traits<T>::Vec &drow, T
         // unit, so every instruction counts: 25 + v_rsq per pair
         T rinv, dist;
         rsqrt_sqrt_f64(d2, rinv, dist);
-        const T res = (dist - delta) * weight01_f64(delta);   // (dist - delta) or 0
+        // (dist - delta) or 0 in ONE instruction: w is 1, or 0 exactly where delta is 0, so
+        // dist * w - delta is dist - delta (the product is exact) or 0 - 0
+        const T res = fma(dist, weight01_f64(delta), -delta);
         s = fma(res, res, s);
         const T coef = res * rinv;  // (d - delta) / d ; the factor 2 is applied in the reduce
         gx = fma(coef, dx, gx); gy = fma(coef, dy, gy); gz = fma(coef, dz, gz);
@@ -1668,7 +1670,7 @@ __device__ __forceinline__ void pair_row(T delta, T xi, T yi, T zi, T xj, T yj, 
     if constexpr (sizeof(T) == 4)
         res = delta > T(0) ? dist - delta : T(0);
     else
-        res = (dist - delta) * weight01_f64(delta);
+        res = fma(dist, weight01_f64(delta), -delta);        // as pair_step<double>
     s = fma(res, res, s);
     const T coef = res * rinv;
     gx = fma(coef, dx, gx);

@@ -283,9 +283,9 @@ BB_API int bb_solver_get_timing(bb_solver *s, double *grad_ms_avg, double *reduc
  * launches (average over consecutive timed iterations; 0 with fewer than two). */
 BB_API int bb_solver_get_step_timing(bb_solver *s, double *step_ms_avg);
 /* What a pair of HIP events costs by itself on the solver's stream: the average time
- * between two events recorded back to back behind a sweep launch (`pairs` of them).  An
- * interval timed by events around a kernel is the kernel plus about this much (2-4 us):
- * bench.py reports its kernel times net of it, and the raw ones beside. */
+ * between two events recorded back to back behind a sweep launch (`pairs` of them): an
+ * upper bound of what an event-timed interval contains besides its kernel (bench.py
+ * reports it beside its event-timed figures; it subtracts nothing). */
 BB_API int bb_solver_measure_event_gap(bb_solver *s, int pairs, double *ms_avg);
 /* Measurement aid: average duration of a kernel that only READS this rank's
  * resident units (same grid, same per-wave chunks, same 8-row window, no
