@@ -63,6 +63,11 @@ BB_ABL_FLAG(kGlobalWindow, false);
 #else
 BB_ABL_FLAG(kGlobalWindow, true);
 #endif
+#ifdef BB_MFMA_ROWSUM          // A/B: fp32 row sums through v_mfma_f32_16x16x4_f32 (as the fp64 unit
+BB_ABL_FLAG(kDppRowSum, false);   // does) instead of the 64-lane DPP tree: 2.7-6 % SLOWER at every
+#else                             // size (profiles/r03_mfma_rowsum_ab.txt), so not the product
+BB_ABL_FLAG(kDppRowSum, true);
+#endif
 #ifdef BB_ABL_NOREFILL_FIRST  // the first unit of a strip does not refill the window (wrong results:
 BB_ABL_FLAG(kNoRefillFirst, true);   // is that unit slow because its refills cannot be issued?)
 #else

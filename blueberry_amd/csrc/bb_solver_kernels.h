@@ -71,7 +71,9 @@ struct Lay;
 template <bool W>
 struct Lay<float, W> {
     static constexpr int LPR = 2, VW = 512, RPU = 4;
-    static constexpr int MIN_WG = 4;            // __launch_bounds__: <= 128 VGPRs
+    static constexpr int MIN_WG = abl::kDppRowSum ? 4 : 2;   // __launch_bounds__: <= 128 VGPRs (the
+                                                // -DBB_MFMA_ROWSUM experiment keeps 12 selectors and
+                                                // an accumulator more: <= 256)
     static constexpr bool SCALAR_XROW = true;   // 12 row coordinates through the scalar cache
 };
 template <>
@@ -388,6 +390,18 @@ __device__ __forceinline__ double swap_sum32(double t) {
     return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
 }
 
+__device__ __forceinline__ float swap_sum16(float t) {
+    const unsigned b = __float_as_uint(t);
+    const auto a = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float swap_sum32(float t) {
+    const unsigned b = __float_as_uint(t);
+    const auto a = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
 template <bool NT, int OP, bool DEFER, typename XR, typename WIN>
 __device__ __forceinline__ void process_unit_f64w(double2 (&d)[8], const XR &xrow,
                                                   const WIN &next,
@@ -491,11 +505,21 @@ __device__ __forceinline__ void pair_step2(f32x2 delta, f32x2 xi, f32x2 yi, f32x
 }
 
 // d[] holds the unit's 8 wave-loads in row order: d[2*r + k] = row r, load k.
+// Row sums: a fixed-tree 64-lane DPP reduction per matrix row (wave_sum_hi3).  Round 3 tried
+// them through the matrix pipe, as the fp64 unit does (-DBB_MFMA_ROWSUM: v_mfma_f32_16x16x4_f32
+// with a 0/1 selector per sum, the unit's 12 sums side by side in one accumulator, 3 adds and two
+// lane swaps at the end): 72 DPP adds fewer per unit, but 164 VGPRs, a different clustering of
+// the refills and the wait for the accumulator at the end of every unit -- 2.7-6 % slower at
+// every size (profiles/r03_mfma_rowsum_ab.txt).  Why it looked promising: at two waves per SIMD
+// the chip runs this kernel at 1.75-1.83 GHz (power) and the SIMD's VALU is then busy most of a
+// unit's time (418 VALU instructions per unit and wave, 32 of them quarter-rate v_rsq_f32);
+// tools/unit_trace.py prints each XCD's clock.
 template <bool NT, int OP, bool DEFER, bool REFILL = true, typename WIN>
 __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&xrow)[12],
                                                  const WIN &next, StripF32 &st,
                                                  double &stress, __amdgpu_buffer_rsrc_t row_rsrc,
-                                                 unsigned row_voff, int stage_idx) {
+                                                 unsigned row_voff, int stage_idx,
+                                                 const float (&sel)[12]) {
     extern __shared__ __attribute__((aligned(16))) float row_lds[];
     f32x2 s2 = {0.f, 0.f};
     // The 12 row sums of the unit are collected into lanes 48..59 of one register
@@ -505,6 +529,7 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&x
     const int slot = (int)(threadIdx.x & 63) - 48;  // value index this lane keeps, if 0..11
     const int comp = slot - 3 * (slot / 3);     // 0,1,2 = x,y,z
     float keep = 0.f;
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float xs = xrow[3 * r], ys = xrow[3 * r + 1], zs = xrow[3 * r + 2];
@@ -520,9 +545,23 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&x
         if constexpr (REFILL) d[2 * r + 1] = next.template load<NT>(2 * r + 1);
         rx += qx; ry += qy; rz += qz;
         float gx = rx.x + rx.y, gy = ry.x + ry.y, gz = rz.x + rz.y;
-        if constexpr (!abl::kNoDpp) wave_sum_hi3(gx, gy, gz);
-        const float mine = comp == 0 ? gx : (comp == 1 ? gy : gz);
-        keep = (slot >= 3 * r && slot < 3 * r + 3) ? mine : keep;
+        if constexpr (abl::kDppRowSum) {
+            if constexpr (!abl::kNoDpp) wave_sum_hi3(gx, gy, gz);
+            const float mine = comp == 0 ? gx : (comp == 1 ? gy : gz);
+            keep = (slot >= 3 * r && slot < 3 * r + 3) ? mine : keep;
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gx, sel[3 * r + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gy, sel[3 * r + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gz, sel[3 * r + 2], acc, 0, 0, 0);
+        }
+    }
+    if constexpr (!abl::kDppRowSum) {
+        // lane (g = lane / 16, j = lane % 16) holds rows 4g..4g+3 of column j: add them, then
+        // the four lane groups (gfx950 lane swaps: VALU, no LDS); every lane with
+        // lane % 16 == v then holds the unit's sum v -- lanes 48..59 keep theirs
+        float t = (acc.x + acc.y) + (acc.z + acc.w);
+        t = swap_sum16(t);
+        keep = swap_sum32(t);
     }
     if constexpr (abl::kNoStore) {
         asm volatile("" ::"v"(keep));
@@ -727,6 +766,9 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
     double sel[6];
 #pragma unroll
     for (int v = 0; v < 6; ++v) sel[v] = (lane & 15) == v ? 1.0 : 0.0;
+    float sel32[12];   // the same for the 12 row sums of an fp32 unit (process_unit_f32)
+#pragma unroll
+    for (int v = 0; v < 12; ++v) sel32[v] = (lane & 15) == v ? 1.f : 0.f;
 
     if (ua < ub) {
         int slot = wave_slots[w].x;
@@ -900,7 +942,7 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
 #pragma unroll
                 for (int q = 0; q < 12; ++q) xs12[q] = xr.get(q);
                 process_unit_f32<NT, OP, DEFER, !(decltype(first)::value && abl::kNoRefillFirst)>(
-                    d, xs12, window_of(u + 1), st, stress, row_rsrc, row_voff, stage_slot);
+                    d, xs12, window_of(u + 1), st, stress, row_rsrc, row_voff, stage_slot, sel32);
             }
             else if constexpr (W && !abl::kF64Generic)
                 process_unit_f64w<NT, OP, DEFER>(d, xr, window_of(u + 1), st.xj, st.gc,
@@ -919,6 +961,15 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
         // stores: hipcc's s_waitcnt counts are static and are merged over every
         // entry of a loop header, and a prologue- or strip-change-shaped entry
         // drains most of the 8-row prefetch window on every iteration.
+        if constexpr (abl::kUnitTrace) {
+            // slots 5 / 7 of the wave: shader clock (s_memtime) and 100-MHz clock when its
+            // loop begins (stored now: nothing is carried through the loop); slot 6 at its end
+            if (lane == 0) {
+                unsigned long long *t8 = reinterpret_cast<unsigned long long *>(stresspart + n_waves_all);
+                t8[(long long)w * 8 + 5] = (unsigned long long)__builtin_amdgcn_s_memtime();
+                t8[(long long)w * 8 + 7] = (unsigned long long)wall_clock64();
+            }
+        }
         int u = ua;
         for (;;) {
             const int curj = dc.y;
@@ -974,6 +1025,10 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
         }
         wave_stamp(stresspart, n_waves_all, w, 2);                    // last unit consumed
         if constexpr (abl::kUnitTrace) {
+            if (lane == 0) {
+                unsigned long long *t8 = reinterpret_cast<unsigned long long *>(stresspart + n_waves_all);
+                t8[(long long)w * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_memtime();
+            }
             // slot k = top of unit k, slot n = end of the last unit; out to HBM behind the stamps
             unit_stamp(ub - ua);
             unit_stamp(ub - ua + 1);

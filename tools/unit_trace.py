@@ -94,6 +94,16 @@ for n in sizes:
                 print("  class %d: xcc ids %s, ends med %.2f max %.2f us, steady per unit med %.3f" % (
                     c, list(ids), 0.01 * numpy.median(t_end[m] - base), 0.01 * (t_end[m].max() - base),
                     0.01 * numpy.median(numpy.diff(u[m, :maxu + 1], axis=1)[:, min(12, maxu - 1):].mean(axis=1))))
+        # the clock each XCD ran at: shader-clock ticks (s_memtime, slots 5 / 6) over the
+        # 100-MHz ticks (slot 7 / 2) of the same stretch
+        dclk = (w8[:, 6] - w8[:, 5]).astype(numpy.float64)
+        drt = (t_loop_end - w8[:, 7]).astype(numpy.float64)
+        mhz = numpy.where(drt > 0, dclk / numpy.maximum(drt, 1) * 100.0, 0.0)
+        for x in ([] if brief else range(8)):
+            m = have & (xcc == x)
+            if m.any():
+                print("  xcd %d: shader clock over the loop med %.0f MHz (p10 %.0f, p90 %.0f)" % (
+                    x, numpy.median(mhz[m]), numpy.percentile(mhz[m], 10), numpy.percentile(mhz[m], 90)))
         for x in ([] if brief else range(8)):
             m = have & (xcc == x)
             if m.any():
