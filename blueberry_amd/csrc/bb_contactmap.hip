@@ -404,6 +404,14 @@ __global__ __launch_bounds__(256) void symv_kernel(const double *__restrict__ m,
 // All loads are 8 bytes per lane, 512 contiguous bytes per wave: rows of an odd-d matrix
 // start 8 bytes off every other time, and 16 loads of a wave are in flight per chunk.
 constexpr int kSvRows = 64, kSvSeg = 4096, kSvGroup = 8;
+// plain loads: the 512-byte segments of a wave are not line-aligned (odd d), neighbouring
+// chunks share their end lines, and a non-temporal load does not leave them in L2 for the
+// neighbour -- 481 against 505 us per product at d = 24,927 (-DBB_CM_SYMV_NT for the A/B)
+#ifdef BB_CM_SYMV_NT
+__device__ __forceinline__ double sv_load(const double *p) { return __builtin_nontemporal_load(p); }
+#else
+__device__ __forceinline__ double sv_load(const double *p) { return *p; }
+#endif
 __global__ __launch_bounds__(256, 2) void symv_upper_kernel(const double *__restrict__ m, int64_t d,
                                                             const double *__restrict__ x,
                                                             const int2 *__restrict__ items,
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void symv_upper_kernel(const double *__rest
             double a[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                a[r] = (in_c && row0 + r < d) ? __builtin_nontemporal_load(m + (row0 + r) * d + c) : 0.0;
+                a[r] = (in_c && row0 + r < d) ? sv_load(m + (row0 + r) * d + c) : 0.0;
             if (c0 < row0 + 16) {
                 // the chunk crosses this wave's rows: below the diagonal nothing counts, on it
                 // only the row side (the column side would count m_ii x_i twice)
