@@ -137,15 +137,15 @@ __device__ __forceinline__ void nt_store(double *p, double v) { *p = v; }
 #else
 __device__ __forceinline__ void nt_store(double *p, double v) { __builtin_nontemporal_store(v, p); }
 #endif
-constexpr int kNT = 128;                  // tile edge
-constexpr int kNQ = kNT / 8;              // rows per thread: 1024 threads = 128 columns x 8
-constexpr int kNormLds = kNT * (kNT + 1) * 8;
-__global__ __launch_bounds__(1024) void normalize128_kernel(double *m, int64_t d, int64_t n_bins,
-                                                            const double *__restrict__ kr,
-                                                            const double *__restrict__ krexp,
-                                                            unsigned n_pairs) {
+// kNT = tile edge (128: one 1024-thread workgroup per CU; 64: 512 threads, up to four per CU)
+template <int kNT>
+__global__ __launch_bounds__(kNT * 8) void normalize128_kernel(double *m, int64_t d, int64_t n_bins,
+                                                               const double *__restrict__ kr,
+                                                               const double *__restrict__ krexp,
+                                                               unsigned n_pairs) {
+    constexpr int kNQ = kNT / 8;          // rows per thread: kNT columns x 8 threads
     extern __shared__ __attribute__((aligned(16))) double ntile[];   // [kNT][kNT + 1]
-    const int tx = threadIdx.x & (kNT - 1), ty = threadIdx.x >> 7;
+    const int tx = threadIdx.x % kNT, ty = threadIdx.x / kNT;
     double nv[kNQ];
     auto fetch = [&](unsigned b) __attribute__((always_inline)) {
         int TJ, TK;
@@ -1027,21 +1027,30 @@ int bb_cm_normalize(bb_cm *cm, int64_t n_bins, const double *KRnorm, const doubl
             e = hipMemcpyAsync(ke.p, KRexpected, (size_t)n_bins * sizeof(double), hipMemcpyHostToDevice, st);
     }
     const char *env = getenv("BB_CM_NORMALIZE_TILE");
-    const bool big = !(env && atoi(env) == 32) && d >= 2 * kNT;   // small maps: more, smaller tiles
+    const int tile = env ? atoi(env) : 128;
+    const bool big = tile != 32 && d >= 256;              // small maps: more, smaller tiles
     if (e == hipSuccess && big) {
-        const uint64_t nt = (uint64_t)((d + kNT - 1) / kNT), pairs = nt * (nt + 1) / 2;
-        static bool attr_done = false;
-        if (!attr_done) {
-            e = hipFuncSetAttribute((const void *)normalize128_kernel,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kNormLds);
-            attr_done = e == hipSuccess;
+        const int nt_edge = tile == 64 ? 64 : 128;
+        const int lds = nt_edge * (nt_edge + 1) * 8;
+        const uint64_t nt = (uint64_t)((d + nt_edge - 1) / nt_edge), pairs = nt * (nt + 1) / 2;
+        static bool attr_done[2] = {false, false};
+        const void *fn = nt_edge == 64 ? (const void *)normalize128_kernel<64>
+                                       : (const void *)normalize128_kernel<128>;
+        if (!attr_done[nt_edge == 64]) {
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_done[nt_edge == 64] = e == hipSuccess;
         }
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cm->device);
-        if (e == hipSuccess)
-            e = bb::launch(normalize128_kernel, dim3((unsigned)std::min<uint64_t>(pairs, (uint64_t)cus)),
-                           dim3(1024), (size_t)kNormLds, st, cm->m, d, n_bins, (const double *)kr.p,
-                           (const double *)ke.p, (unsigned)pairs);
+        const char *envw = getenv("BB_CM_NORMALIZE_WGS");
+        const uint64_t per_cu = envw ? (uint64_t)atoi(envw) : (nt_edge == 64 ? 4 : 1);
+        const unsigned grid = (unsigned)std::min<uint64_t>(pairs, (uint64_t)cus * per_cu);
+        if (e == hipSuccess && nt_edge == 64)
+            e = bb::launch(normalize128_kernel<64>, dim3(grid), dim3(512), (size_t)lds, st, cm->m, d, n_bins,
+                           (const double *)kr.p, (const double *)ke.p, (unsigned)pairs);
+        else if (e == hipSuccess)
+            e = bb::launch(normalize128_kernel<128>, dim3(grid), dim3(1024), (size_t)lds, st, cm->m, d,
+                           n_bins, (const double *)kr.p, (const double *)ke.p, (unsigned)pairs);
     } else if (e == hipSuccess) {
         const uint64_t nt = (uint64_t)((d + kT - 1) / kT);
         if (nt * (nt + 1) / 2 > 0x7fffffffull)
