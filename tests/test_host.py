@@ -382,3 +382,37 @@ def test_n_iter_beyond_the_device_history_is_refused_up_front():
     with pytest.raises(ValueError, match="2\\*\\*20"):
         bb.StructureSolver(n_iter=(1 << 20) + 1)
     bb.StructureSolver(n_iter=1 << 20)
+
+
+def test_entry_loops_without_python_loops_keep_last_wins():
+    """`ContactMap.from_arrays` and `FithicContactMap.to_matrix` place their entries without a
+    Python loop over them; of several entries for one cell the LAST stays,
+    as in the reference's loops (`datatypes.pyx:268-271, 376-386`) -- checked against the loop."""
+    from blueberry_amd.datatypes import _assign_last_wins
+    rng = numpy.random.default_rng(21)
+    for _ in range(10):
+        d, n = int(rng.integers(1, 40)), int(rng.integers(0, 600))
+        r, c, v = rng.integers(0, d, n), rng.integers(0, d, n), rng.random(n)
+        want = numpy.zeros((d, d))
+        for k in range(n):
+            want[r[k], c[k]] = v[k]
+        got = numpy.zeros((d, d))
+        _assign_last_wins(got, r, c, v)
+        assert numpy.array_equal(got, want)
+    # through the public entry points, duplicates included
+    res = 1000
+    mids = (rng.integers(0, 12, (300, 2)) * res + res // 2).astype(float)
+    contacts = numpy.column_stack([mids, rng.random(300)])
+    cm = bb.ContactMap.from_arrays("c", 1, res, contacts, n_bins=12)
+    want = numpy.zeros((13, 13))
+    for m1, m2, val in contacts:
+        j, k = int((m1 - res / 2) / res), int((m2 - res / 2) / res)
+        want[j, k] = val
+        want[k, j] = val
+    assert numpy.array_equal(cm.matrix, want)
+    fm = bb.FithicContactMap.from_array(numpy.column_stack([mids, rng.random((300, 3))]), res)
+    got = fm.to_matrix("p", n_bins=12)
+    want = numpy.zeros((13, 13))
+    for m1, m2, _, p, _q in fm.map:
+        want[int((m1 - res / 2) / res), int((m2 - res / 2) / res)] = p
+    assert numpy.array_equal(got, want)
