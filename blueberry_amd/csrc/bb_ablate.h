@@ -68,6 +68,16 @@ BB_ABL_FLAG(kDppRowSum, false);   // does) instead of the 64-lane DPP tree: 2.7-
 #else                             // size (profiles/r03_mfma_rowsum_ab.txt), so not the product
 BB_ABL_FLAG(kDppRowSum, true);
 #endif
+#ifdef BB_SCHED_REFILL         // experiment: sched_group_barrier, one refill per n VALU instructions
+constexpr int kSchedRefill = BB_SCHED_REFILL;
+#else
+constexpr int kSchedRefill = 0;
+#endif
+#ifdef BB_DPP_ROWSUM           // A/B: fp32 row sums by the 64-lane DPP tree of rounds 1-2 (18 VALU
+BB_ABL_FLAG(kSwapRowSum, false);  // instructions per row) instead of the lane swaps (10):
+#else                             // profiles/r03_swap_rowsum_ab.txt
+BB_ABL_FLAG(kSwapRowSum, true);
+#endif
 #ifdef BB_ABL_NOREFILL_FIRST  // the first unit of a strip does not refill the window (wrong results:
 BB_ABL_FLAG(kNoRefillFirst, true);   // is that unit slow because its refills cannot be issued?)
 #else

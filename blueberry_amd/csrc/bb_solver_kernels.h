@@ -402,6 +402,35 @@ __device__ __forceinline__ float swap_sum32(float t) {
 }
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// The three sums of a matrix row (x, y, z components) over the 64 lanes in 10 VALU
+// instructions instead of 18 (round 3; the sweep is issue-bound at the clock the chip runs it
+// at, see the kernel's comment).  gfx950's lane swaps exchange half of one register with the
+// other half of a second one, so ONE swap + ONE add both adds across the halves and sorts two
+// sums apart: after the 32-lane step the lower half holds x, the upper y (z is folded with
+// itself); after the 16-lane step the even 16-lane rows hold x | y, the odd ones z; four DPP
+// steps then add up each row.  Result: the row's x total in every lane 0..15, z in 16..31
+// and 48..63, y in 32..47.  Fixed tree: bitwise reproducible.
+__device__ __forceinline__ float row_sum3_swap(float gx, float gy, float gz) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(gx), __float_as_uint(gy), false, false);
+    const float xy = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(gz), __float_as_uint(gz), false, false);
+    const float zz = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    const auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(xy), __float_as_uint(zz), false, false);
+    float w = __uint_as_float(c[0]) + __uint_as_float(c[1]);
+    w += dpp_get<0xB1, 0xF>(w);   // quad_perm [1,0,3,2]
+    w += dpp_get<0x4E, 0xF>(w);   // quad_perm [2,3,0,1]
+    w += dpp_get<0x141, 0xF>(w);  // row_half_mirror
+    w += dpp_get<0x140, 0xF>(w);  // row_mirror
+    return w;
+}
+// which of a unit's 12 row sums a lane keeps under row_sum3_swap: row r = lane % 16 (< 4) of
+// component x (lanes 0..3), z (16..19) or y (32..35); -1: none
+__device__ __forceinline__ int swap_rowsum_slot(int lane) {
+    const int r = lane & 15;
+    if (r >= 4 || lane >= 48) return -1;
+    return 3 * r + (lane < 16 ? 0 : (lane < 32 ? 2 : 1));
+}
+
 template <bool NT, int OP, bool DEFER, typename XR, typename WIN>
 __device__ __forceinline__ void process_unit_f64w(double2 (&d)[8], const XR &xrow,
                                                   const WIN &next,
@@ -530,6 +559,8 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&x
     const int comp = slot - 3 * (slot / 3);     // 0,1,2 = x,y,z
     float keep = 0.f;
     f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    // (row_sum3_swap) the matrix row of the unit whose sum this lane keeps, or -1
+    const int swap_role = (((threadIdx.x & 15) < 4) && ((threadIdx.x & 63) < 48)) ? (int)(threadIdx.x & 15) : -1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float xs = xrow[3 * r], ys = xrow[3 * r + 1], zs = xrow[3 * r + 2];
@@ -545,7 +576,10 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&x
         if constexpr (REFILL) d[2 * r + 1] = next.template load<NT>(2 * r + 1);
         rx += qx; ry += qy; rz += qz;
         float gx = rx.x + rx.y, gy = ry.x + ry.y, gz = rz.x + rz.y;
-        if constexpr (abl::kDppRowSum) {
+        if constexpr (abl::kSwapRowSum) {
+            const float w = row_sum3_swap(gx, gy, gz);
+            keep = (swap_role == r) ? w : keep;
+        } else if constexpr (abl::kDppRowSum) {
             if constexpr (!abl::kNoDpp) wave_sum_hi3(gx, gy, gz);
             const float mine = comp == 0 ? gx : (comp == 1 ? gy : gz);
             keep = (slot >= 3 * r && slot < 3 * r + 3) ? mine : keep;
@@ -555,7 +589,7 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&x
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(gz, sel[3 * r + 2], acc, 0, 0, 0);
         }
     }
-    if constexpr (!abl::kDppRowSum) {
+    if constexpr (!abl::kDppRowSum && !abl::kSwapRowSum) {
         // lane (g = lane / 16, j = lane % 16) holds rows 4g..4g+3 of column j: add them, then
         // the four lane groups (gfx950 lane swaps: VALU, no LDS); every lane with
         // lane % 16 == v then holds the unit's sum v -- lanes 48..59 keep theirs
@@ -573,6 +607,16 @@ __device__ __forceinline__ void process_unit_f32(float4 (&d)[8], const float (&x
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(keep), row_rsrc, row_voff, 0, 0);
     }
     stress += (double)(s2.x + s2.y);
+    if constexpr (abl::kSchedRefill > 0) {
+        // experiment (-DBB_SCHED_REFILL=n): ask the scheduler for a refill after every n VALU
+        // instructions, i.e. right behind the half row it replaces, instead of where it
+        // puts them by itself (two in the middle of the unit, six at its end)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x002, abl::kSchedRefill, 0);   // VALU
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                   // one VMEM read
+        }
+    }
 }
 
 __device__ __forceinline__ void load_strip_f32(StripF32 &st, const float *__restrict__ X, int j0,
@@ -919,10 +963,14 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
                 // (k - park_from) and their store is dropped (every lane out of range).
                 const int k = u - ua;
                 const bool parked = DEFER && k >= park_from;
-                const bool mine = lane >= 48 && lane < 60;
-                row_voff = (mine && !parked) ? (unsigned)k * kRowBytes + (unsigned)(lane - 48) * 4u
+                // which of the unit's 12 sums this lane holds: lanes 48..59 after the DPP tree,
+                // lanes 0..3 / 16..19 / 32..35 after the lane swaps (row_sum3_swap)
+                const int sl12 = abl::kSwapRowSum ? swap_rowsum_slot(lane)
+                                                  : (lane >= 48 && lane < 60 ? lane - 48 : -1);
+                const bool mine = sl12 >= 0;
+                row_voff = (mine && !parked) ? (unsigned)k * kRowBytes + (unsigned)sl12 * 4u
                                              : kDropOffset;
-                stage_slot = stage0 + ((mine && parked) ? (k - park_from) * 12 + (lane - 48)
+                stage_slot = stage0 + ((mine && parked) ? (k - park_from) * 12 + sl12
                                                         : cap_units * 12 + (lane & 3));
             } else if constexpr (W && !abl::kF64Generic) {
                 // fp64, 2 x 512 units: lanes 48..53 hold one of the unit's 6 sums each
