@@ -937,6 +937,15 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
                 t_prev = t_now;
             }
         };
+        // fp32: which of a unit's 12 row sums this lane holds -- lanes 0..3 / 16..19 / 32..35
+        // after the lane swaps (row_sum3_swap), lanes 48..59 after the DPP tree -- and what
+        // follows from it for the unit's store offset and parking slot
+        const int f32_sl12 = abl::kSwapRowSum ? swap_rowsum_slot(lane)
+                                              : (lane >= 48 && lane < 60 ? lane - 48 : -1);
+        const unsigned f32_voff_lane = f32_sl12 >= 0 ? (unsigned)f32_sl12 * 4u : 0x40000000u;
+        const int f32_lds_dummy = stage0 + cap_units * 12 + (lane & 3);
+        const int f32_lds_real = f32_sl12 >= 0 ? stage0 + f32_sl12 : f32_lds_dummy;
+        const int f32_m12 = f32_sl12 >= 0 ? 12 : 0;
         auto unit_step = [&](int u, auto first) __attribute__((always_inline)) {
             unit_stamp(u - ua);
             if constexpr (WPB == 8) {
@@ -961,17 +970,16 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
                 // fp32: lanes 48..59 hold one of the unit's 12 sums each.  Units before
                 // park_from are stored directly; the later ones are parked in LDS slot
                 // (k - park_from) and their store is dropped (every lane out of range).
+                // per-lane parts are loop constants (f32_voff_lane, f32_lds_real / _dummy,
+                // f32_m12: below the lambda's captures), per-unit parts scalar: one v_add, one
+                // v_cndmask, one v_mad per unit instead of a chain of selects.  A store is out
+                // of range (dropped) unless the lane holds a sum AND the unit is not parked:
+                // 0x40000000 from either side puts the offset beyond any chunk.
                 const int k = u - ua;
                 const bool parked = DEFER && k >= park_from;
-                // which of the unit's 12 sums this lane holds: lanes 48..59 after the DPP tree,
-                // lanes 0..3 / 16..19 / 32..35 after the lane swaps (row_sum3_swap)
-                const int sl12 = abl::kSwapRowSum ? swap_rowsum_slot(lane)
-                                                  : (lane >= 48 && lane < 60 ? lane - 48 : -1);
-                const bool mine = sl12 >= 0;
-                row_voff = (mine && !parked) ? (unsigned)k * kRowBytes + (unsigned)sl12 * 4u
-                                             : kDropOffset;
-                stage_slot = stage0 + ((mine && parked) ? (k - park_from) * 12 + sl12
-                                                        : cap_units * 12 + (lane & 3));
+                row_voff = f32_voff_lane + (parked ? 0x40000000u : (unsigned)k * kRowBytes);
+                stage_slot = (parked ? f32_lds_real : f32_lds_dummy) +
+                             (parked ? k - park_from : 0) * f32_m12;
             } else if constexpr (W && !abl::kF64Generic) {
                 // fp64, 2 x 512 units: lanes 48..53 hold one of the unit's 6 sums each
                 // (parking as in fp32; an LDS slot is 4 bytes, a sum takes two)
