@@ -1448,3 +1448,29 @@ def test_eigenvector_reports_no_convergence():
     assert abs(err.value.eigenvalue - 2.0) < 1e-4 and err.value.eigenvector.shape == (d,)
     v = cm.eigenvector(tol=1e-4)                      # a reachable tolerance converges
     assert abs(cm.eigenvalue_ - 2.0) < 1e-4 and abs(numpy.linalg.norm(v) - 1) < 1e-12
+
+
+# ---- the knobs that keep older code paths alive still give the oracle's result --------------
+@pytest.mark.parametrize("env", [{"BB_REDUCE_OLD": "1"}, {"BB_REDUCE_SLICES": "4"},
+                                 {"BB_REDUCE_SLICES": "8"}, {"BB_ARITH_DESC": "0"},
+                                 {"BB_WG_MAP": "77"}, {"BB_WG_MAP": "-1"},
+                                 {"BB_WAVES_PER_CU": "8"}, {"BB_WAVES_PER_CU": "4", "BB_PAIR": "0"}])
+@pytest.mark.parametrize("dtype,tol", [("float32", 1e-5), ("float64", 1e-12)])
+def test_sweep_and_reduce_variants_vs_oracle(oracle, monkeypatch, env, dtype, tol):
+    """The unit sweep with each of its run-time variants -- the round-2 two-stage reduce, the
+    sliced reduce with 4 and 8 slices, table descriptors, permuted / XCD-contiguous block
+    maps, 8 and 4 waves per CU -- against the oracle (N=5,000: 13 strips, several list
+    lengths)."""
+    monkeypatch.setenv("BB_ROW_OWNER_MAX", "0")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n, iters = 5000, 5
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    w[10:40, 3000:3300] = 0.0                     # a hole: "no constraint" inside full tiles
+    w[3000:3300, 10:40] = 0.0
+    x0 = _oracle.noisy_init(xs)
+    X_ref, h_ref = oracle.solve(w, x0, iters, 1.0 / (2 * n), f64=(dtype == "float64"))
+    s = bb.StructureSolver(n_iter=iters, dtype=dtype, kind="wish").fit(w, init=x0)
+    assert numpy.abs(s.stress_ / h_ref - 1).max() < tol
+    assert numpy.abs(s.structure_ - X_ref).max() < tol * numpy.abs(X_ref).max()
