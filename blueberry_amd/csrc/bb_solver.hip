@@ -1898,10 +1898,21 @@ int spectral_init_t(bb_solver *s, int n_iter, const double *v0) {
     jacobi3(m, z);
     int order[3] = {0, 1, 2};
     std::sort(order, order + 3, [&](int a, int b) { return m[a * 4] > m[b * 4]; });
+    // An eigenvector's sign is arbitrary: every Ritz vector V z_c is turned to the side of
+    // the start's first column p (p . V z_c >= 0), as solver.py's spectral_init does, so one
+    // seed gives one start whichever of the two computed it.
+    BB_HIP_CHECK(hipMemsetAsync(dZ, 0, (size_t)n3 * 8, st));
+    BB_HIP_CHECK(hipMemcpyAsync(dZ, v0, (size_t)n * 24, hipMemcpyHostToDevice, st));
+    BB_HIP_CHECK(bb::launch(gram3_kernel<double, double>, dim3(1), dim3(1024), 0, st, (const double *)dV,
+                            (const double *)dZ, n, dS));
+    BB_TRY(fetch_sums());                                  // sums[r * 3 + 0] = V[:, r] . p
     Affine3 f = ident;
     for (int c = 0; c < 3; ++c) {
         const double lam = m[order[c] * 4] > 0.0 ? m[order[c] * 4] : 0.0;
-        for (int r = 0; r < 3; ++r) f.m[r * 3 + c] = z[r * 3 + order[c]] * sqrt(lam);
+        double side = 0.0;
+        for (int r = 0; r < 3; ++r) side += z[r * 3 + order[c]] * sums[r * 3];
+        const double sg = side < 0.0 ? -1.0 : 1.0;
+        for (int r = 0; r < 3; ++r) f.m[r * 3 + c] = sg * z[r * 3 + order[c]] * sqrt(lam);
     }
     BB_HIP_CHECK(bb::launch(affine3_kernel<double, T>, gvec, b256, 0, st, (const double *)dV,
                             (T *)s->d_X, n, n_pad, f));

@@ -678,13 +678,19 @@ def spectral_init(eng, n, world, n_iter=40, seed=0):
                 dist.all_reduce(t)
         return -0.5 * (W - W.mean(axis=0))
 
-    V = numpy.linalg.qr(numpy.random.default_rng(seed).standard_normal((n, 3)))[0]
+    G0 = numpy.random.default_rng(seed).standard_normal((n, 3))
+    V = numpy.linalg.qr(G0)[0]
     for _ in range(int(n_iter)):
         V = numpy.linalg.qr(apply_B(V))[0]
     Z = apply_B(V)
     evals, evecs = numpy.linalg.eigh(0.5 * (V.T @ Z + Z.T @ V))       # Rayleigh-Ritz, 3x3
     order = numpy.argsort(evals)[::-1]
-    return (V @ evecs[:, order]) * numpy.sqrt(numpy.maximum(evals[order], 0.0))
+    U = V @ evecs[:, order]
+    # an eigenvector's sign is arbitrary (numpy's eigh and the device path's Jacobi sweeps
+    # need not agree): every Ritz vector is turned to the side of the start's first column,
+    # here and in bb_solver_spectral_init, so one seed gives one start on every world size
+    U = U * numpy.where(U.T @ G0[:, 0] < 0.0, -1.0, 1.0)
+    return U * numpy.sqrt(numpy.maximum(evals[order], 0.0))
 
 
 def _all_ranks(ok):

@@ -180,6 +180,14 @@ def test_spectral_init_host_loop_is_classical_mds():
                            distributed=False, engine=OracleEngine).fit(w)
     assert numpy.abs(_oracle.wish_from_coords(s.structure_) - w).max() < 1e-6 * w.max()
     assert s.stress_[0] < 1e-10 * (w ** 2).sum()
+    # the signs of the Ritz vectors are pinned (to the side of the start's first column), so
+    # the start is one configuration and not one of its eight mirror images
+    from blueberry_amd.solver import spectral_init
+    eng = OracleEngine(n, "float64")
+    eng.set_wish_dense(w, "wish", 3.0)
+    x0 = spectral_init(eng, n, 1, seed=0)
+    p = numpy.random.default_rng(0).standard_normal((n, 3))[:, 0]
+    assert (x0.T @ p > 0).all()
 
 
 def test_count_band_regions_input_checks():
