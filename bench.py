@@ -405,6 +405,10 @@ def main():
                 "host": "gloo, host-staged (rehearsal)", None: "none"}[eng._comm_state]
     comm_trial = eng._comm_trial
     rccl_world = eng.comm_world() if eng._comm_state == "rccl" else None
+    if eng._comm_state == "peer":
+        # "one launch": reduce + push + wait + sum + update per workgroup; "two launches"
+        # where ranks share a GPU (include/blueberry_hip.h)
+        eng_comm += ", " + eng.peer_form()
 
     eng.close()
     if rank == 0:

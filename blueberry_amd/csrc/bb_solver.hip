@@ -80,6 +80,8 @@ struct bb_solver {
     std::vector<void *> peer_mapped;        // arenas of all ranks as mapped here (own = peer_arena)
     std::vector<void *> peer_opened;        // the ones that came from hipIpcOpenMemHandle
     void *d_peer_table = nullptr;           // PeerTable<T>[2], one per parity
+    void *d_peer_table_x = nullptr;         // PeerTableX<T>[2]: the one-launch exchange
+    bool peer_fused = true;                 // reduce_exchange_kernel (BB_PEER_FUSED=0: two launches)
     PeerState *d_peer_state = nullptr;      // sticky failure flag + last complete exchange
     int peer_clock_khz = 100000;            // constant-rate clock behind wall_clock64()
     unsigned *d_peer_counter = nullptr;
@@ -107,6 +109,8 @@ struct bb_solver {
 namespace {
 
 void comm_release(bb_solver *s, bool destroy);   // the communicator cache, further down
+int64_t peer_xflags_offset(const bb_solver *s);  // the peer arena's layout, further down
+int64_t peer_xpoison_offset(const bb_solver *s);
 
 constexpr int64_t kHistCap = 1 << 20;
 constexpr size_t kMaxTimedLaunches = 4096;
@@ -476,9 +480,37 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
     return BB_OK;
 }
 
+template <typename T>
+void fill_reduce_params(bb_solver *s, ReduceParams<T> &p, int mode, double lr, double *stress_out,
+                        double scale);
+
+// The peer exchange in one launch (reduce_exchange_kernel): the caller has bumped peer_seq.
 template <typename T, bool W>
-int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, double scale) {
+int launch_exchange_t(bb_solver *s, double lr, double *stress_out) {
     ReduceParams<T> p;
+    fill_reduce_params<T>(s, p, kReducePeer, lr, stress_out, 2.0);
+    const int64_t es = sizeof(T);
+    const unsigned segs = 3 * Lay<T, W>::VW / kRedWG;
+    const dim3 grid((unsigned)s->L.n_blocks, segs);
+    const PeerTableX<T> *xt = (const PeerTableX<T> *)s->d_peer_table_x + (s->peer_seq & 1);
+    const char *base = (const char *)s->peer_arena;
+    const T *arena = (const T *)(base + (int64_t)(s->peer_seq & 1) * s->world * s->peer_slot_elems * es);
+    const unsigned long long *my_flags = (const unsigned long long *)(base + peer_xflags_offset(s));
+    const unsigned long long *my_poison = (const unsigned long long *)(base + peer_xpoison_offset(s));
+    if (s->red_slices == 4)
+        BB_HIP_CHECK(bb::launch(reduce_exchange_kernel<T, W, 4>, grid, dim3(128 * 4), 0, s->stream, p,
+                                (const int64_t *)s->d_red_lists, s->red_stride, xt, arena, my_flags,
+                                my_poison, s->peer_slot_elems, s->d_peer_state, s->peer_limit_ticks));
+    else
+        BB_HIP_CHECK(bb::launch(reduce_exchange_kernel<T, W, 8>, grid, dim3(128 * 8), 0, s->stream, p,
+                                (const int64_t *)s->d_red_lists, s->red_stride, xt, arena, my_flags,
+                                my_poison, s->peer_slot_elems, s->d_peer_state, s->peer_limit_ticks));
+    return BB_OK;
+}
+
+template <typename T>
+void fill_reduce_params(bb_solver *s, ReduceParams<T> &p, int mode, double lr, double *stress_out,
+                        double scale) {
     p.part = (const T *)s->d_part;
     p.stresspart = s->d_stresspart;
     p.X = (T *)s->d_X;
@@ -502,6 +534,15 @@ int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, doubl
         p.seq = s->peer_seq;
         p.n_peers = s->world;
     }
+    p.blk_ptr = nullptr;
+    p.blk_chunk = nullptr;
+    p.mode = mode;
+}
+
+template <typename T, bool W>
+int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, double scale) {
+    ReduceParams<T> p;
+    fill_reduce_params<T>(s, p, mode, lr, stress_out, scale);
     const unsigned segs = 3 * Lay<T, W>::VW / kRedWG;   // workgroups per block of 3*vw elements
     if (s->red_slices > 0) {
         // one launch: every list whole, 128 elements x 4 or 8 slices per workgroup
@@ -538,6 +579,9 @@ int launch_grad(bb_solver *s, int op = kOpStress, const void *x_in = nullptr) {
 }
 int launch_reduce(bb_solver *s, int mode, double lr, double *stress_out, double scale = 2.0) {
     return BB_BY_LAYOUT(s, launch_reduce_t, s, mode, lr, stress_out, scale);
+}
+int launch_exchange(bb_solver *s, double lr, double *stress_out) {
+    return BB_BY_LAYOUT(s, launch_exchange_t, s, lr, stress_out);
 }
 
 hipEvent_t *timing_slot(bb_solver *s) {
@@ -687,6 +731,7 @@ struct PeerHandle {
     int64_t pid;
     uint64_t raw;            // the exporter's own pointer (same-process ranks only)
     int32_t rank, world, dtype, device;
+    uint64_t pci;            // PCI domain << 32 | bus << 16 | device: which GPU, whatever its index
 };
 static_assert(sizeof(PeerHandle) <= BB_PEER_HANDLE_BYTES, "handle blob too small");
 static_assert(offsetof(PeerTable<float>, flag) == kMaxPeers * sizeof(void *) &&
@@ -696,6 +741,18 @@ constexpr uint64_t kPeerMagic = 0x6262706565723031ull;  // "bbpeer01"
 
 int64_t peer_flags_offset(const bb_solver *s) {
     return 2 * (int64_t)s->world * s->peer_slot_elems * bb::elem_size(s->dtype);
+}
+// the one-launch exchange (reduce_exchange_kernel): one flag per (source rank, workgroup of
+// the reduce grid) behind the per-rank flags, then one poison word per source rank
+int64_t peer_items(const bb_solver *s) { return s->L.n_blocks * (3 * s->L.vw / kRedWG); }
+int64_t peer_xflags_offset(const bb_solver *s) {
+    return peer_flags_offset(s) + bb::round_up((int64_t)s->world * 64, 256);
+}
+int64_t peer_xpoison_offset(const bb_solver *s) {
+    return peer_xflags_offset(s) + bb::round_up((int64_t)s->world * peer_items(s) * 8, 256);
+}
+int64_t peer_arena_size(const bb_solver *s) {
+    return peer_xpoison_offset(s) + bb::round_up((int64_t)s->world * 64, 256);
 }
 
 template <typename T>
@@ -711,6 +768,18 @@ int build_peer_tables(bb_solver *s) {
         }
     BB_TRY(dev_alloc((char **)&s->d_peer_table, (int64_t)sizeof(tab)));
     BB_HIP_CHECK(hipMemcpy(s->d_peer_table, tab, sizeof(tab), hipMemcpyHostToDevice));
+    PeerTableX<T> tx[2];
+    memset(tx, 0, sizeof(tx));
+    for (int par = 0; par < 2; ++par)
+        for (int q = 0; q < s->world; ++q) {
+            char *base = (char *)s->peer_mapped[q];
+            tx[par].dst[q] = tab[par].dst[q];
+            tx[par].flag[q] = (unsigned long long *)(base + peer_xflags_offset(s)) +
+                              (int64_t)s->rank * peer_items(s);
+            tx[par].poison[q] = (unsigned long long *)(base + peer_xpoison_offset(s)) + 8 * s->rank;
+        }
+    BB_TRY(dev_alloc((char **)&s->d_peer_table_x, (int64_t)sizeof(tx)));
+    BB_HIP_CHECK(hipMemcpy(s->d_peer_table_x, tx, sizeof(tx), hipMemcpyHostToDevice));
     return BB_OK;
 }
 
@@ -800,6 +869,7 @@ int bb_solver_destroy(bb_solver *s) {
     for (void *m : s->peer_opened) hipIpcCloseMemHandle(m);
     hipFree(s->peer_arena);
     hipFree(s->d_peer_table);
+    hipFree(s->d_peer_table_x);
     hipFree(s->d_peer_state);
     hipFree(s->d_peer_counter);
     for (hipEvent_t e : s->ev) hipEventDestroy(e);
@@ -1278,7 +1348,7 @@ int bb_solver_peer_export(bb_solver *s, void *handle_out) {
     BB_TRY(bb::enter_device(s->device));
     const int64_t es = bb::elem_size(s->dtype);
     s->peer_slot_elems = bb::round_up(3 * s->L.n_pad + 2, 256 / es);
-    s->peer_arena_bytes = peer_flags_offset(s) + (int64_t)s->world * 64;
+    s->peer_arena_bytes = peer_arena_size(s);
     // Uncached: written by the peers' kernels while ours is running, so nothing of
     // it may live in this GPU's L2.  (RCCL allocates its own buffers the same way.)
     hipError_t e = hipExtMallocWithFlags(&s->peer_arena, (size_t)s->peer_arena_bytes,
@@ -1313,6 +1383,16 @@ int bb_solver_peer_export(bb_solver *s, void *handle_out) {
     h.world = s->world;
     h.dtype = s->dtype;
     h.device = s->device;
+    {
+        int dom = 0, bus = 0, dev = 0;
+        if (hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, s->device) != hipSuccess ||
+            hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, s->device) != hipSuccess ||
+            hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, s->device) != hipSuccess) {
+            (void)hipGetLastError();
+            dom = bus = dev = 0;       // unknown: ranks then count as sharing one GPU (the safe side)
+        }
+        h.pci = ((uint64_t)(uint32_t)dom << 32) | ((uint64_t)(bus & 0xffff) << 16) | (uint64_t)(dev & 0xffff);
+    }
     memset(handle_out, 0, BB_PEER_HANDLE_BYTES);
     memcpy(handle_out, &h, sizeof(h));
     return BB_OK;
@@ -1324,9 +1404,12 @@ int bb_solver_peer_connect(bb_solver *s, const void *handles) {
     if (s->peer_connected) return bb::fail(BB_ERR_STATE, "bb_solver_peer_connect: already connected");
     BB_TRY(bb::enter_device(s->device));
     s->peer_mapped.assign((size_t)s->world, nullptr);
+    std::map<uint64_t, int> ranks_on_gpu;      // how many ranks sit on each GPU of the node
+    int most_on_one_gpu = 1;
     for (int r = 0; r < s->world; ++r) {
         PeerHandle h;
         memcpy(&h, (const char *)handles + (size_t)r * BB_PEER_HANDLE_BYTES, sizeof(h));
+        most_on_one_gpu = std::max(most_on_one_gpu, ++ranks_on_gpu[h.pci]);
         if (h.magic != kPeerMagic || h.rank != r || h.world != s->world || h.dtype != s->dtype ||
             h.arena_bytes != s->peer_arena_bytes || h.slot_elems != s->peer_slot_elems)
             return bb::fail(BB_ERR_INVALID, "bb_solver_peer_connect: handle " + std::to_string(r) +
@@ -1378,6 +1461,20 @@ int bb_solver_peer_connect(bb_solver *s, const void *handles) {
     }
     s->peer_limit_ticks = ms * s->peer_clock_khz;
     s->peer_seq = 0;
+    {
+        // The one-launch exchange (reduce_exchange_kernel) has every workgroup wait for its
+        // peers' copies of itself: fine with one rank per GPU (workgroups are dispatched in
+        // order and push before they wait), not when ranks SHARE a GPU and the waiting
+        // workgroups of some can keep the sweep of another off the device (three ranks at
+        // N=7,000 fp64 on one GPU: every CU held a waiting workgroup and 16 KB of its LDS, the
+        // third rank's sweep wants 150 KB per workgroup, time-out).  Every rank sees every
+        // handle (PCI ids), so all of them decide alike: any GPU with two ranks on it -- a
+        // rehearsal -- and it is the two-launch form.  BB_PEER_FUSED=0|1 overrides (the same
+        // on every rank; small problems on a shared GPU do run in one launch).
+        const char *env = getenv("BB_PEER_FUSED");
+        s->peer_fused = env ? atoi(env) != 0 : most_on_one_gpu == 1;
+        if (s->red_slices <= 0) s->peer_fused = false;
+    }
     s->peer_connected = true;
     BB_HIP_CHECK(hipDeviceSynchronize());
     return BB_OK;
@@ -1390,6 +1487,13 @@ int bb_solver_peer_set_timeout(bb_solver *s, int64_t milliseconds) {
     if (!s->peer_connected)
         return bb::fail(BB_ERR_STATE, "bb_solver_peer_set_timeout: not connected");
     s->peer_limit_ticks = (long long)milliseconds * s->peer_clock_khz;
+    return BB_OK;
+}
+
+int bb_solver_peer_form(bb_solver *s, int *one_launch) {
+    BB_REQUIRE(s != nullptr && one_launch != nullptr, "bb_solver_peer_form: NULL argument");
+    if (!s->peer_connected) return bb::fail(BB_ERR_STATE, "bb_solver_peer_form: not connected");
+    *one_launch = (s->peer_fused && s->red_slices > 0) ? 1 : 0;
     return BB_OK;
 }
 
@@ -1430,6 +1534,13 @@ int bb_solver_iterate_peer(bb_solver *s, int64_t iters, double lr) {
         BB_TRY(launch_grad(s));
         if (ev) BB_HIP_CHECK(hipEventRecord(ev[1], s->stream));
         s->peer_seq++;
+        if (s->peer_fused && s->red_slices > 0) {
+            // one launch: reduce, push, wait, sum, update (reduce_exchange_kernel)
+            BB_TRY(launch_exchange(s, lr, s->d_stress_hist + s->hist_n));
+            if (ev) BB_HIP_CHECK(hipEventRecord(ev[2], s->stream));
+            s->hist_n++;
+            continue;
+        }
         BB_TRY(launch_reduce(s, kReducePeer, 0.0, nullptr));
         if (ev) BB_HIP_CHECK(hipEventRecord(ev[2], s->stream));
         const char *arena = (const char *)s->peer_arena +

@@ -1469,6 +1469,181 @@ __global__ __launch_bounds__(128 * S) void reduce_sliced_kernel(ReduceParams<T> 
     }
 }
 
+// ---- the peer exchange in ONE launch: reduce, push, wait, sum, update (round 3) --------
+// reduce_sliced_kernel in peer mode + peer_receive_kernel are two launches with a check-in of
+// every workgroup in between (release fence, two atomic counters, the last arriver raises
+// the rank's flag), and the receiving launch has one wave wait for the flags of all ranks
+// before any of its workgroups may move: 13.4 + ~9 us at a 1/8 share of N=50,000 against
+// 8 us for the reduce that applies its own sum (tools/exchange_timing.py).  Here the unit of
+// exchange is what a workgroup reduces anyway -- 128 gradient elements of one block -- and
+// the workgroup sees its elements through: it sums its lists, stores the 128 sums into its
+// rank's slot on every peer, raises ITS OWN flag there (one 8-byte word per workgroup and
+// source rank; the pushing wave releases and signals, no counter, no barrier between
+// workgroups), waits for the same flag from every rank in its own arena, adds the R
+// partials in rank order and updates its 128 coordinates.  Nobody waits for anybody's
+// slowest workgroup but the owner of the same 128 elements.
+//   Progress: workgroups are dispatched in index order and each pushes BEFORE it waits, so
+// the lowest unfinished index is resident (or next in line) on every rank and has pushed
+// wherever it is resident: it completes everywhere, frees its slot, and so on.  That needs
+// each rank's GPU to itself (the product's model: one process per GPU); ranks SHARING one
+// device can fill its wave slots with waiting workgroups while the rank they wait for still
+// sweeps -- rehearsals of large problems on one GPU use the two-launch form (BB_PEER_FUSED=0).
+//   Failure: a wait that runs into the time limit, a peer's poison word, or this rank's own
+// sticky status end the workgroup without an update; it sets the status, leaves the poison
+// word on every peer, and every workgroup still waiting -- here and there -- leaves within
+// a poll.  Unlike the two-launch form this one can fail PARTIALLY (some 128-element pieces
+// of the step applied, others not): the status is sticky, bb_solver_peer_status reports it,
+// and the coordinates of a failed solver are not a result.
+template <typename T>
+struct PeerTableX {
+    T *dst[kMaxPeers];                       // this rank's slot in rank q's arena (one parity)
+    unsigned long long *flag[kMaxPeers];     // this rank's row of workgroup flags in rank q's arena
+    unsigned long long *poison[kMaxPeers];   // this rank's poison word in rank q's arena
+};
+
+template <typename T, bool W, int S>
+__global__ __launch_bounds__(128 * S) void reduce_exchange_kernel(
+    ReduceParams<T> p, const int64_t *__restrict__ lists, int list_stride,
+    const PeerTableX<T> *__restrict__ xt, const T *arena, const unsigned long long *my_flags,
+    const unsigned long long *my_poison, int64_t slot_elems, PeerState *state, long long limit) {
+    constexpr int CH = 3 * Lay<T, W>::VW;
+    const int tid = threadIdx.x;
+    const int el = tid & (kRedWG - 1);
+    const int sl = __builtin_amdgcn_readfirstlane(tid >> 7);      // slice: uniform per wave
+    const int b = blockIdx.x;
+    const int e = (int)blockIdx.y * kRedWG + el;                  // element of the block, < CH
+    const int item = b * (int)gridDim.y + (int)blockIdx.y;        // this workgroup's flag
+    const int n_items = (int)(gridDim.x * gridDim.y);
+    const int R = p.n_peers;
+    __shared__ __attribute__((aligned(16))) T meet[S][kRedWG];
+    __shared__ double sh[128 * S];
+    __shared__ int go;
+    // a failed rank pushes nothing and leaves X alone (its peers have its poison word);
+    // ONE thread asks, the first barrier below tells the others: the word can change under us
+    const int dead_here =
+        tid == 0 ? __hip_atomic_load(&state->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+
+    const int lps = list_stride / S;                              // a multiple of 16
+    const int64_t *list = lists + (int64_t)b * list_stride + (int64_t)sl * lps;
+    const int64_t o = (int64_t)b * CH + e;
+    T xo = T(0), vo = T(0);
+    if (sl == 0) { xo = p.X[o]; vo = p.V[o]; }                    // early: independent
+    T acc = T(0);
+    for (int k = 0; k < lps; k += 16) {
+        T v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = p.part[list[k + q] + e];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc += v[q];
+    }
+    meet[sl][el] = acc;
+    const bool first = b == 0 && blockIdx.y == 0;
+    if (first) {
+        double s = 0.0;                       // the stress: per-wave partials of the sweep, fixed tree
+        for (int i = tid; i < p.n_waves; i += 128 * S) s += p.stresspart[i];
+        sh[tid] = s;
+    }
+    if (__syncthreads_or(dead_here) != 0) return;
+    if (first) {
+        for (int off = 64 * S; off > 0; off >>= 1) {
+            if (tid < off) sh[tid] += sh[tid + off];
+            __syncthreads();
+        }
+    }
+    if (sl == 0) {
+        T tot = meet[0][el];
+#pragma unroll
+        for (int q = 1; q < S; ++q) tot += meet[q][el];
+        meet[0][el] = p.scale * tot;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        // wave 0: push, release, signal, wait
+        typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
+        constexpr int NV = kRedWG * (int)sizeof(T) / 16;          // 32 or 64 lanes
+        const int lane = tid;
+        if (lane < NV) {
+            const vec_t val = ((const vec_t *)meet[0])[lane];
+            for (int q = 0; q < R; ++q)
+                ((vec_t *)(xt->dst[q] + (int64_t)b * CH + (int64_t)blockIdx.y * kRedWG))[lane] = val;
+        }
+        if (first && lane == 0) {
+            const double Sx = sh[0];
+            const T hi = (T)Sx, lo = (T)(Sx - (double)hi);
+            for (int q = 0; q < R; ++q) {
+                xt->dst[q][3 * p.n_pad] = hi;
+                xt->dst[q][3 * p.n_pad + 1] = lo;
+            }
+        }
+        // (one release per workgroup: it is a write-back of the XCD's L2)
+        if (lane < R)
+            __hip_atomic_store(xt->flag[lane] + item, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // lanes [0, R): the flag of this workgroup from rank `lane`; [R, 2R): that rank's
+        // poison word; lane 2R: this rank's own status.  Relaxed system-scope loads (they go
+        // past the caches of this device), one acquire when the wait is over.
+        const unsigned long long *addr = lane < R ? my_flags + (int64_t)lane * n_items + item
+                                                  : my_poison + 8 * (lane < 2 * R ? lane - R : 0);
+        bool ok = false;
+        const long long t0 = wall_clock64();
+        for (;;) {
+            unsigned long long f = p.seq;
+            if (lane < 2 * R)
+                f = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else if (lane == 2 * R)
+                f = (unsigned long long)__hip_atomic_load(&state->status, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+            const bool bad = (lane >= R && lane < 2 * R && f == kPeerPoison) || (lane == 2 * R && f != 0);
+            if (__ballot(bad) != 0) break;
+            const bool here = lane >= R || f >= p.seq;
+            if (__ballot(here) == __ballot(1)) { ok = true; break; }
+            if (__ballot(wall_clock64() - t0 > limit) != 0) break;   // wave-uniform exits only
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (ok) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // system scope
+        } else {
+            if (lane < R)
+                __hip_atomic_store(xt->poison[lane], kPeerPoison, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane == 0)
+                __hip_atomic_store(&state->status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) go = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!go) return;
+    // X <- X + (mu V - lr * sum over ranks, in rank order).  The arena is uncached memory read
+    // with system-scope loads, issued behind the barrier: not older than the flags.
+    if (sl == 0) {
+        T g = T(0);
+        for (int r0 = 0; r0 < R; r0 += 8) {
+            T v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                v[q] = r0 + q < R ? __hip_atomic_load(arena + (int64_t)(r0 + q) * slot_elems + o,
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                  : T(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (r0 + q < R) g += v[q];
+        }
+        const T vv = p.mu * vo - p.lr * g;
+        p.V[o] = vv;
+        p.X[o] = xo + vv;
+    }
+    if (first && tid == 0) {
+        double Sx = 0.0;
+        const int64_t n3 = 3 * p.n_pad;
+        for (int r = 0; r < R; ++r)
+            Sx += (double)__hip_atomic_load(arena + (int64_t)r * slot_elems + n3, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_SYSTEM) +
+                  (double)__hip_atomic_load(arena + (int64_t)r * slot_elems + n3 + 1, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_SYSTEM);
+        *p.stress_out = Sx;
+        __hip_atomic_store(&state->verdict, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // Peer exchange, receiving side -- one launch.  Wave 0 of workgroup 0 waits until every
 // source rank's flag has reached `seq` and publishes the outcome (state->verdict = seq);
 // wave 0 of every other workgroup polls that LOCAL word and the sticky status, so the

@@ -262,6 +262,13 @@ class HipEngine(object):
     def comm_abort(self):
         _lib.check(self._lib.bb_solver_comm_abort(self._h), "bb_solver_comm_abort")
 
+    def peer_form(self):
+        """'one launch' (reduce, push, wait, sum and update in one kernel) or 'two launches'
+        (include/blueberry_hip.h, peer exchange)."""
+        one = _lib.c_int()
+        _lib.check(self._lib.bb_solver_peer_form(self._h, one), "bb_solver_peer_form")
+        return "one launch" if one.value else "two launches"
+
     def peer_set_timeout(self, milliseconds):
         _lib.check(self._lib.bb_solver_peer_set_timeout(self._h, int(milliseconds)),
                    "bb_solver_peer_set_timeout")

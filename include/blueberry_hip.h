@@ -222,10 +222,26 @@ BB_API int bb_comm_cache_clear(void);
  *                           (BB_PEER_TIMEOUT_MS, default 10000) or a peer reported
  *                           its own failure: this call reports BB_ERR_STATE
  *   bb_solver_peer_set_timeout  change that limit (a short one for a trial run)
- * A failure is decided ONCE per iteration, by one wave, for the whole update: X is
- * advanced by a complete step or not at all.  The failed rank stops pushing and
- * leaves a poison flag on every peer, so their next wait fails at once as well --
- * no rank goes on consuming partials of coordinates that no longer move.
+ *   bb_solver_peer_form     1 = the one-launch form below, 0 = the two launches above
+ * One-launch form (the default with one rank per GPU): the unit of exchange is what one
+ * workgroup of the reduce sums anyway, 128 gradient elements of one block.  The workgroup
+ * stores them into its rank's slot on every peer, raises its OWN flag there (one word per
+ * workgroup and source rank), waits for the same flag from every rank, adds the `world`
+ * partials in rank order and updates its 128 coordinates: { grad, exchange } per iteration,
+ * and nobody waits for any workgroup but the owners of the same 128 elements.  Every
+ * workgroup pushes before it waits and workgroups start in index order, so the lowest
+ * unfinished one can always finish -- if each rank has its GPU to itself.  bb_solver_peer_connect
+ * sees from the handles (PCI ids) whether ranks SHARE a GPU (a rehearsal) and then keeps the
+ * two-launch form: waiting workgroups of one rank can keep another rank's sweep off the
+ * device.  BB_PEER_FUSED=0|1 overrides, identically on every rank.
+ * Failure.  Two-launch form: decided ONCE per iteration, by one wave, for the whole update:
+ * X is advanced by a complete step or not at all.  One-launch form: every workgroup decides
+ * for its 128 elements, so a rank that dies in the middle of an exchange can leave its
+ * peers with part of a step applied; when nothing of an exchange arrives (a rank that is
+ * late, stalled or gone) no workgroup applies anything.  Either way the failed rank stops
+ * pushing and leaves a poison word on every peer, so their waits fail at once as well -- no
+ * rank goes on consuming partials of coordinates that no longer move -- the status is
+ * sticky, and the coordinates of a solver whose status is not 0 are not a result.
  * The handles travel by whatever the caller has (MPI_Allgather, torch.distributed,
  * a file).  All ranks must be on one node with peer access between their GPUs. */
 #define BB_PEER_HANDLE_BYTES 128
@@ -234,6 +250,7 @@ BB_API int bb_solver_peer_connect(bb_solver *s, const void *handles_rank_order);
 BB_API int bb_solver_iterate_peer(bb_solver *s, int64_t iters, double lr);
 BB_API int bb_solver_peer_status(bb_solver *s, int *status);
 BB_API int bb_solver_peer_set_timeout(bb_solver *s, int64_t milliseconds);
+BB_API int bb_solver_peer_form(bb_solver *s, int *one_launch);
 
 /* Host-staged access to the exchange buffer, widened to float64, for callers
  * whose collective runs on host memory (MPI, gloo): read after bb_solver_grad,

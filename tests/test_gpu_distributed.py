@@ -35,8 +35,13 @@ def _worker(rank, world, port, n, k, dtype, q, comm="host"):
         sys.path.insert(0, ROOT)
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        os.environ["BB_COMM"] = comm
+        os.environ["BB_COMM"] = comm.split("-")[0]
         os.environ["BB_PEER_TIMEOUT_MS"] = "5000"
+        if comm == "peer-one-launch":
+            # ranks that share a GPU get the two-launch exchange by default (waiting workgroups
+            # of one rank can keep another's sweep off the device); a small problem is safe
+            os.environ["BB_PEER_FUSED"] = "1"
+        comm = comm.split("-")[0]
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import blueberry_amd as bb
@@ -61,6 +66,8 @@ def _worker(rank, world, port, n, k, dtype, q, comm="host"):
     # flags and partials written by the other process's kernels
     ("float64", 1e-12, 2, "peer", 1300), ("float32", 1e-5, 2, "peer", 1300),
     ("float32", 1e-5, 4, "peer", 1300),
+    # the same with the whole exchange in one launch (what ranks with a GPU each get)
+    ("float64", 1e-12, 2, "peer-one-launch", 1300), ("float32", 1e-5, 4, "peer-one-launch", 1300),
     # fp64 above 4096 bins: the 2 x 512 units (MFMA row reduction, parked row sums), an odd
     # number of ranks, heavy-ball momentum
     ("float64", 1e-12, 3, "peer", 7000)])
@@ -84,7 +91,7 @@ def test_ranks_share_one_gpu(dtype, tol, world, comm, n):
     xs = _oracle.random_walk(n)
     w = _oracle.wish_from_coords(xs)
     one = bb.StructureSolver(n_iter=k, dtype=dtype, kind="wish", distributed=False,
-                             momentum=0.3 if comm == "peer" else 0.0)
+                             momentum=0.3 if comm.startswith("peer") else 0.0)
     one.fit(w, init=_oracle.noisy_init(xs))
     for rank, X, hist, band in results:
         assert numpy.abs(X - one.structure_).max() < tol * numpy.abs(one.structure_).max()
@@ -251,12 +258,16 @@ def _peer_engines(world, n, dtype, wish, x0, mu=0.0):
     return engs
 
 
+@pytest.mark.parametrize("form", ["one launch", "two launches"])
 @pytest.mark.parametrize("dtype,tol,world", [("float32", 1e-5, 2), ("float64", 1e-12, 2),
                                              ("float32", 1e-5, 3)])
-def test_peer_exchange_in_one_process(dtype, tol, world, monkeypatch):
+def test_peer_exchange_in_one_process(dtype, tol, world, form, monkeypatch):
     """Ranks on separate streams of one process: every iteration of every rank is
-    enqueued up front, the kernels meet through the arenas' flags."""
+    enqueued up front, the kernels meet through the arenas' flags.  Both forms of the
+    exchange (include/blueberry_hip.h): reduce + push + wait + sum + update in one launch,
+    workgroup by workgroup, and the two launches with one flag per rank."""
     monkeypatch.setenv("BB_PEER_TIMEOUT_MS", "5000")
+    monkeypatch.setenv("BB_PEER_FUSED", "1" if form == "one launch" else "0")
     from blueberry_amd.solver import HipEngine
     from tests import _oracle
     n, k = 1100, 7
@@ -265,6 +276,7 @@ def test_peer_exchange_in_one_process(dtype, tol, world, monkeypatch):
     x0 = _oracle.noisy_init(xs)
     lr = 1.0 / (2 * n)
     engs = _peer_engines(world, n, dtype, w, x0, mu=0.2)
+    assert all(e.peer_form() == form for e in engs)
     for it in (3, k - 3):                       # two calls: the sequence carries over
         for e in engs:
             e.iterate_peer(it, lr)
@@ -286,10 +298,12 @@ def test_peer_exchange_in_one_process(dtype, tol, world, monkeypatch):
         assert h.shape == h1.shape and numpy.abs(h / h1 - 1).max() < tol
 
 
-def test_peer_exchange_times_out_cleanly(monkeypatch):
+@pytest.mark.parametrize("form", ["one launch", "two launches"])
+def test_peer_exchange_times_out_cleanly(form, monkeypatch):
     """A rank whose peer never delivers must not hang: the wait is bounded, the
     update is skipped as a whole, the failure is sticky and reported."""
     monkeypatch.setenv("BB_PEER_TIMEOUT_MS", "200")
+    monkeypatch.setenv("BB_PEER_FUSED", "1" if form == "one launch" else "0")
     from tests import _oracle
     n = 600
     xs = _oracle.random_walk(n)
@@ -303,16 +317,20 @@ def test_peer_exchange_times_out_cleanly(monkeypatch):
         e.close()
 
 
-def test_stalled_rank_fails_every_rank_and_leaves_x_whole(monkeypatch):
+@pytest.mark.parametrize("form", ["one launch", "two launches"])
+def test_stalled_rank_fails_every_rank_and_leaves_x_whole(form, monkeypatch):
     """with every workgroup of the update polling for itself, a
     time-out could apply a step to part of X, and the timed-out rank kept feeding its
-    peers partials of coordinates that no longer moved.  Now one wave decides per
-    launch, and a failed rank poisons its flag on every peer.  Three ranks, rank 2
+    peers partials of coordinates that no longer moved.  Two launches: one wave decides
+    per launch; one launch: a workgroup applies its 128 elements only when all ranks'
+    copies of them have arrived, and of a rank that never runs nothing arrives.  Either
+    way a failed rank poisons its word on every peer.  Three ranks, rank 2
     stalled for good: rank 0 (200 ms limit) times out; rank 1 (60 s limit) must fail
     right behind it -- through the poison, not through its own clock -- and on both X
     is exactly the start, on every element."""
     import time
     monkeypatch.setenv("BB_PEER_TIMEOUT_MS", "60000")
+    monkeypatch.setenv("BB_PEER_FUSED", "1" if form == "one launch" else "0")
     from tests import _oracle
     n = 5000                                       # 30 workgroups in the update launch
     xs = _oracle.random_walk(n)

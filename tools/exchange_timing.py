@@ -28,8 +28,10 @@ for n in sizes:
     xs = numpy.cumsum(rng.standard_normal((n, 3)), axis=0)
     x0 = xs + 0.5 * rng.standard_normal(xs.shape)
     for name, world, comm in (("fused", 1, "auto"), ("rccl", 2, "rccl"), ("peer", 2, "peer"),
-                              ("torch", 2, "torch")):
+                              ("peer2", 2, "peer"), ("torch", 2, "torch")):
         os.environ["BB_COMM"] = comm
+        # peer: reduce + push + wait + sum + update in one launch; peer2: the two-launch form
+        os.environ["BB_PEER_FUSED"] = "0" if name == "peer2" else "1"
         e = HipEngine(n, "float32")
         e.set_wish_from_coords(xs)
         e.set_coords(x0)
