@@ -298,6 +298,38 @@ def test_peer_exchange_in_one_process(dtype, tol, world, form, monkeypatch):
         assert h.shape == h1.shape and numpy.abs(h / h1 - 1).max() < tol
 
 
+def test_peer_exchange_forms_agree_bit_for_bit_over_a_long_run(monkeypatch):
+    """600 iterations of three ranks through the one-launch exchange and through the two
+    launches: both add the ranks' partials in rank order, so every rank of either run must
+    hold the same bits -- a workgroup that ever read a slot before its data had landed (or a
+    parity that was overwritten too early) would show here."""
+    monkeypatch.setenv("BB_PEER_TIMEOUT_MS", "20000")
+    from tests import _oracle
+    n, k, world = 2600, 600, 3
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    x0 = _oracle.noisy_init(xs)
+    runs = {}
+    for form in ("one launch", "two launches"):
+        monkeypatch.setenv("BB_PEER_FUSED", "1" if form == "one launch" else "0")
+        engs = _peer_engines(world, n, "float32", w, x0, mu=0.3)
+        assert engs[0].peer_form() == form
+        for chunk in (1, 199, 400):
+            for e in engs:
+                e.iterate_peer(chunk, 1.0 / (2 * n))
+        got = []
+        for e in engs:
+            assert e.peer_status() == 0
+            got.append((e.get_coords(), e.stress_history()))
+            e.close()
+        for X, h in got[1:]:
+            assert numpy.array_equal(X, got[0][0]) and numpy.array_equal(h, got[0][1])
+        runs[form] = got[0]
+    assert numpy.array_equal(runs["one launch"][0], runs["two launches"][0])
+    assert numpy.array_equal(runs["one launch"][1], runs["two launches"][1])
+    assert runs["one launch"][1].shape == (k,) and runs["one launch"][1][-1] < runs["one launch"][1][0]
+
+
 @pytest.mark.parametrize("form", ["one launch", "two launches"])
 def test_peer_exchange_times_out_cleanly(form, monkeypatch):
     """A rank whose peer never delivers must not hang: the wait is bounded, the
