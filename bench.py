@@ -377,6 +377,9 @@ def main():
             "exchange_update_gaps_ms": max(0.0, tim["step_ms"] - tim["grad_ms"] - tim["reduce_ms"])
             if tim["step_ms"] > 0 else None,
             "wall_ms_per_step": dt_mine / a.steps * 1e3}
+    if eng._comm_state == "peer" and eng.peer_form() == "one launch":
+        # the exchange (push, wait for the peers, sum, update) is INSIDE the reduce launch
+        mine["reduce_includes_exchange"] = True
     per_rank = [mine]
     if use_dist and world > 1:
         per_rank = [None] * world
