@@ -1066,6 +1066,18 @@ def test_solver_fp32_chr1_10kb_sized_vs_oracle(oracle):
     s = bb.StructureSolver(n_iter=k, lr=lr, dtype="float32", kind="wish").fit(w, init=x0)
     assert numpy.abs(s.stress_ / h_ref - 1).max() < 1e-5
     assert _rel(s.structure_, X_ref) < 1e-5
+    # the same matrix split over three ranks (separate streams of this process, partials
+    # through the peer arenas): every rank against the oracle, not against another GPU run
+    # (oracle-anchored multi-rank runs stopped at N = 7,000)
+    from tests.test_gpu_distributed import _peer_engines
+    engs = _peer_engines(3, n, "float32", w, x0)
+    for e in engs:
+        e.iterate_peer(k, lr)
+    for e in engs:
+        assert e.peer_status() == 0
+        assert numpy.abs(e.stress_history() / h_ref - 1).max() < 1e-5
+        assert _rel(e.get_coords(), X_ref) < 1e-5
+        e.close()
 
 
 # ---- API state behaviour -----------------------------------------------------------------
