@@ -546,9 +546,6 @@ int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, doubl
     const unsigned segs = 3 * Lay<T, W>::VW / kRedWG;   // workgroups per block of 3*vw elements
     if (s->red_slices > 0) {
         // one launch: every list whole, 128 elements x 4 or 8 slices per workgroup
-        p.blk_ptr = nullptr;
-        p.blk_chunk = nullptr;
-        p.mode = mode;
         const dim3 grid = mode == kReduceStressOnly ? dim3(1, 1) : dim3((unsigned)s->L.n_blocks, segs);
         if (s->red_slices == 4)
             BB_HIP_CHECK(bb::launch(reduce_sliced_kernel<T, W, 4>, grid, dim3(128 * 4), 0, s->stream,
