@@ -109,8 +109,7 @@ struct bb_solver {
 namespace {
 
 void comm_release(bb_solver *s, bool destroy);   // the communicator cache, further down
-int64_t peer_xflags_offset(const bb_solver *s);  // the peer arena's layout, further down
-int64_t peer_xpoison_offset(const bb_solver *s);
+int64_t peer_xpoison_offset(const bb_solver *s);  // the peer arena's layout, further down
 
 constexpr int64_t kHistCap = 1 << 20;
 constexpr size_t kMaxTimedLaunches = 4096;
@@ -495,16 +494,15 @@ int launch_exchange_t(bb_solver *s, double lr, double *stress_out) {
     const PeerTableX<T> *xt = (const PeerTableX<T> *)s->d_peer_table_x + (s->peer_seq & 1);
     const char *base = (const char *)s->peer_arena;
     const T *arena = (const T *)(base + (int64_t)(s->peer_seq & 1) * s->world * s->peer_slot_elems * es);
-    const unsigned long long *my_flags = (const unsigned long long *)(base + peer_xflags_offset(s));
     const unsigned long long *my_poison = (const unsigned long long *)(base + peer_xpoison_offset(s));
     if (s->red_slices == 4)
         BB_HIP_CHECK(bb::launch(reduce_exchange_kernel<T, W, 4>, grid, dim3(128 * 4), 0, s->stream, p,
-                                (const int64_t *)s->d_red_lists, s->red_stride, xt, arena, my_flags,
-                                my_poison, s->peer_slot_elems, s->d_peer_state, s->peer_limit_ticks));
+                                (const int64_t *)s->d_red_lists, s->red_stride, xt, arena, my_poison,
+                                s->peer_slot_elems, s->d_peer_state, s->peer_limit_ticks));
     else
         BB_HIP_CHECK(bb::launch(reduce_exchange_kernel<T, W, 8>, grid, dim3(128 * 8), 0, s->stream, p,
-                                (const int64_t *)s->d_red_lists, s->red_stride, xt, arena, my_flags,
-                                my_poison, s->peer_slot_elems, s->d_peer_state, s->peer_limit_ticks));
+                                (const int64_t *)s->d_red_lists, s->red_stride, xt, arena, my_poison,
+                                s->peer_slot_elems, s->d_peer_state, s->peer_limit_ticks));
     return BB_OK;
 }
 
@@ -739,14 +737,11 @@ constexpr uint64_t kPeerMagic = 0x6262706565723031ull;  // "bbpeer01"
 int64_t peer_flags_offset(const bb_solver *s) {
     return 2 * (int64_t)s->world * s->peer_slot_elems * bb::elem_size(s->dtype);
 }
-// the one-launch exchange (reduce_exchange_kernel): one flag per (source rank, workgroup of
-// the reduce grid) behind the per-rank flags, then one poison word per source rank
-int64_t peer_items(const bb_solver *s) { return s->L.n_blocks * (3 * s->L.vw / kRedWG); }
-int64_t peer_xflags_offset(const bb_solver *s) {
-    return peer_flags_offset(s) + bb::round_up((int64_t)s->world * 64, 256);
-}
+// the one-launch exchange (reduce_exchange_kernel): one poison word per source rank behind
+// the per-rank flags of the two-launch form (its data words say by themselves whether they
+// have arrived)
 int64_t peer_xpoison_offset(const bb_solver *s) {
-    return peer_xflags_offset(s) + bb::round_up((int64_t)s->world * peer_items(s) * 8, 256);
+    return peer_flags_offset(s) + bb::round_up((int64_t)s->world * 64, 256);
 }
 int64_t peer_arena_size(const bb_solver *s) {
     return peer_xpoison_offset(s) + bb::round_up((int64_t)s->world * 64, 256);
@@ -771,8 +766,6 @@ int build_peer_tables(bb_solver *s) {
         for (int q = 0; q < s->world; ++q) {
             char *base = (char *)s->peer_mapped[q];
             tx[par].dst[q] = tab[par].dst[q];
-            tx[par].flag[q] = (unsigned long long *)(base + peer_xflags_offset(s)) +
-                              (int64_t)s->rank * peer_items(s);
             tx[par].poison[q] = (unsigned long long *)(base + peer_xpoison_offset(s)) + 8 * s->rank;
         }
     BB_TRY(dev_alloc((char **)&s->d_peer_table_x, (int64_t)sizeof(tx)));
@@ -1360,7 +1353,11 @@ int bb_solver_peer_export(bb_solver *s, void *handle_out) {
         return bb::fail(BB_ERR_NOMEM, std::string("bb_solver_peer_export: arena: ") +
                                           hipGetErrorString(e));
     }
-    BB_HIP_CHECK(hipMemset(s->peer_arena, 0, (size_t)s->peer_arena_bytes));
+    // every data word starts out EMPTY (all bits set: reduce_exchange_kernel), flags and poison
+    // words at 0
+    BB_HIP_CHECK(hipMemset(s->peer_arena, 0xff, (size_t)peer_flags_offset(s)));
+    BB_HIP_CHECK(hipMemset((char *)s->peer_arena + peer_flags_offset(s), 0,
+                           (size_t)(s->peer_arena_bytes - peer_flags_offset(s))));
     BB_HIP_CHECK(hipDeviceSynchronize());
     PeerHandle h;
     memset(&h, 0, sizeof(h));

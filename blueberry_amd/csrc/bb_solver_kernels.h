@@ -1473,51 +1473,132 @@ __global__ __launch_bounds__(128 * S) void reduce_sliced_kernel(ReduceParams<T> 
 // reduce_sliced_kernel in peer mode + peer_receive_kernel are two launches with a check-in of
 // every workgroup in between (release fence, two atomic counters, the last arriver raises
 // the rank's flag), and the receiving launch has one wave wait for the flags of all ranks
-// before any of its workgroups may move: 13.4 + ~9 us at a 1/8 share of N=50,000 against
-// 8 us for the reduce that applies its own sum (tools/exchange_timing.py).  Here the unit of
-// exchange is what a workgroup reduces anyway -- 128 gradient elements of one block -- and
-// the workgroup sees its elements through: it sums its lists, stores the 128 sums into its
-// rank's slot on every peer, raises ITS OWN flag there (one 8-byte word per workgroup and
-// source rank; the pushing wave releases and signals, no counter, no barrier between
-// workgroups), waits for the same flag from every rank in its own arena, adds the R
-// partials in rank order and updates its 128 coordinates.  Nobody waits for anybody's
-// slowest workgroup but the owner of the same 128 elements.
-//   Progress: workgroups are dispatched in index order and each pushes BEFORE it waits, so
-// the lowest unfinished index is resident (or next in line) on every rank and has pushed
+// before any of its workgroups may move: 10 + 6.6 us at a 1/8 share of N=50,000 against
+// 5.1 us for the reduce that applies its own sum (kernel trace of tools/exchange_timing.py).
+// Here the unit of exchange is what a workgroup reduces anyway -- 128 gradient elements of
+// one block -- and the two waves that hold those sums see them through: each thread stores
+// its element into its rank's slot on every peer, then reads the same element of every
+// rank's slot in its own arena until all of them have ARRIVED, adds them in rank order,
+// updates its coordinate and marks the words it consumed as empty again.
+//   No flags, no fences: a word says by itself whether it has arrived.  An empty slot word
+// holds kPeerEmpty -- all bits set, a NaN no arithmetic produces (the sender turns a sum that
+// should ever carry those bits into the canonical NaN) -- and a 4- or 8-byte store is seen
+// whole or not at all; nothing else is published with it, so nothing has to be ordered
+// against it: relaxed system-scope stores and loads on uncached memory, one round trip from
+// "the peer's store has landed" to "the sum is known".  The slots start out empty
+// (bb_solver_peer_export), a consumer empties what it has read, and with two parities a
+// word is written again only two exchanges later, by a sender that has seen this rank's NEXT
+// push -- issued a whole launch after the emptying store.
+//   Nobody waits for anybody's slowest workgroup but the owners of the same 64 elements.
+// Progress: workgroups are dispatched in index order and each pushes BEFORE it waits, so the
+// lowest unfinished index is resident (or next in line) on every rank and has pushed
 // wherever it is resident: it completes everywhere, frees its slot, and so on.  That needs
 // each rank's GPU to itself (the product's model: one process per GPU); ranks SHARING one
-// device can fill its wave slots with waiting workgroups while the rank they wait for still
-// sweeps -- rehearsals of large problems on one GPU use the two-launch form (BB_PEER_FUSED=0).
+// device can fill its wave slots and LDS with waiting workgroups while the rank they wait for
+// still sweeps -- bb_solver_peer_connect keeps the two-launch form then (BB_PEER_FUSED).
 //   Failure: a wait that runs into the time limit, a peer's poison word, or this rank's own
-// sticky status end the workgroup without an update; it sets the status, leaves the poison
-// word on every peer, and every workgroup still waiting -- here and there -- leaves within
-// a poll.  Unlike the two-launch form this one can fail PARTIALLY (some 128-element pieces
-// of the step applied, others not): the status is sticky, bb_solver_peer_status reports it,
-// and the coordinates of a failed solver are not a result.
+// sticky status end the wave without an update; it sets the status, leaves the poison word
+// on every peer, and every wave still waiting -- here and there -- leaves within a poll.
+// Unlike the two-launch form this one can fail PARTIALLY (some 64-element pieces of the
+// step applied, others not): the status is sticky, bb_solver_peer_status reports it, and the
+// coordinates of a failed solver are not a result.
 template <typename T>
 struct PeerTableX {
     T *dst[kMaxPeers];                       // this rank's slot in rank q's arena (one parity)
-    unsigned long long *flag[kMaxPeers];     // this rank's row of workgroup flags in rank q's arena
     unsigned long long *poison[kMaxPeers];   // this rank's poison word in rank q's arena
 };
+
+__device__ __forceinline__ bool peer_word_empty(float v) { return __float_as_uint(v) == 0xffffffffu; }
+__device__ __forceinline__ bool peer_word_empty(double v) { return __double_as_longlong(v) == -1ll; }
+__device__ __forceinline__ float peer_empty_word(float) { return __uint_as_float(0xffffffffu); }
+__device__ __forceinline__ double peer_empty_word(double) { return __longlong_as_double(-1ll); }
+// what is pushed must not look empty: a sum with exactly those bits becomes the canonical NaN
+template <typename T>
+__device__ __forceinline__ T peer_sendable(T v) {
+    return peer_word_empty(v) ? (T)__builtin_nanf("") : v;
+}
+
+// One wave's wait for `n_words` words per lane of every rank: base + r * slot_elems (+ 1 for
+// the second word), r < R.  Returns true with the rank-ordered sum(s) in out0 / out1 and the
+// words emptied; false after a time-out, a poison word or a set status (status set, peers
+// poisoned).  `active` lanes have an element; the others only take part in the votes.
+template <typename T, int NW>
+__device__ __forceinline__ bool peer_wait_sum(const T *base, bool active, int R, int64_t slot_elems,
+                                              const PeerTableX<T> *xt, const unsigned long long *my_poison,
+                                              PeerState *state, long long limit, T &sum, double &pair_sum) {
+    const int lane = threadIdx.x & 63;
+    T v[NW][kMaxPeers];
+    bool ok = false;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        bool missing = false;
+#pragma unroll
+        for (int r = 0; r < kMaxPeers; ++r) {
+            if (r < R) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    v[w][r] = active ? __hip_atomic_load(base + (int64_t)r * slot_elems + w, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_SYSTEM)
+                                     : T(0);
+                    missing |= peer_word_empty(v[w][r]);
+                }
+            }
+        }
+        // lanes [0, R): rank `lane`'s poison word in this arena; lane R: this rank's status
+        unsigned long long f = 0;
+        if (lane < R)
+            f = __hip_atomic_load(my_poison + 8 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else if (lane == R)
+            f = (unsigned long long)__hip_atomic_load(&state->status, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+        if (__ballot(lane < R ? f == kPeerPoison : f != 0) != 0) break;
+        if (__ballot(missing) == 0) { ok = true; break; }
+        if (__ballot(wall_clock64() - t0 > limit) != 0) break;      // wave-uniform exits only
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok) {
+        if (lane < R)
+            __hip_atomic_store(xt->poison[lane], kPeerPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (lane == 0)
+            __hip_atomic_store(&state->status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
+    // NW = 1: the element's sum over the ranks, in rank order, in T.  NW = 2: the words are a
+    // (hi, lo) pair of one double per rank: their sum in double, rank by rank
+    T s0 = T(0);
+    double s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < kMaxPeers; ++r) {
+        if (r < R) {
+            s0 += v[0][r];
+            if (NW > 1) s2 += (double)v[0][r] + (double)v[NW - 1][r];
+            if (active) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+                    __hip_atomic_store(const_cast<T *>(base) + (int64_t)r * slot_elems + w,
+                                       peer_empty_word(T(0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    sum = s0;
+    pair_sum = s2;
+    return true;
+}
 
 template <typename T, bool W, int S>
 __global__ __launch_bounds__(128 * S) void reduce_exchange_kernel(
     ReduceParams<T> p, const int64_t *__restrict__ lists, int list_stride,
-    const PeerTableX<T> *__restrict__ xt, const T *arena, const unsigned long long *my_flags,
-    const unsigned long long *my_poison, int64_t slot_elems, PeerState *state, long long limit) {
+    const PeerTableX<T> *__restrict__ xt, const T *arena, const unsigned long long *my_poison,
+    int64_t slot_elems, PeerState *state, long long limit) {
     constexpr int CH = 3 * Lay<T, W>::VW;
     const int tid = threadIdx.x;
     const int el = tid & (kRedWG - 1);
     const int sl = __builtin_amdgcn_readfirstlane(tid >> 7);      // slice: uniform per wave
     const int b = blockIdx.x;
     const int e = (int)blockIdx.y * kRedWG + el;                  // element of the block, < CH
-    const int item = b * (int)gridDim.y + (int)blockIdx.y;        // this workgroup's flag
-    const int n_items = (int)(gridDim.x * gridDim.y);
     const int R = p.n_peers;
     __shared__ __attribute__((aligned(16))) T meet[S][kRedWG];
     __shared__ double sh[128 * S];
-    __shared__ int go;
     // a failed rank pushes nothing and leaves X alone (its peers have its poison word);
     // ONE thread asks, the first barrier below tells the others: the word can change under us
     const int dead_here =
@@ -1551,96 +1632,41 @@ __global__ __launch_bounds__(128 * S) void reduce_exchange_kernel(
         }
     }
     if (sl == 0) {
+        // the two waves that own the workgroup's 128 elements: push, wait, sum, update
         T tot = meet[0][el];
 #pragma unroll
         for (int q = 1; q < S; ++q) tot += meet[q][el];
-        meet[0][el] = p.scale * tot;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        // wave 0: push, release, signal, wait
-        typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
-        constexpr int NV = kRedWG * (int)sizeof(T) / 16;          // 32 or 64 lanes
-        const int lane = tid;
-        if (lane < NV) {
-            const vec_t val = ((const vec_t *)meet[0])[lane];
-            for (int q = 0; q < R; ++q)
-                ((vec_t *)(xt->dst[q] + (int64_t)b * CH + (int64_t)blockIdx.y * kRedWG))[lane] = val;
+        const T mine = peer_sendable(p.scale * tot);
+        for (int q = 0; q < R; ++q)
+            __hip_atomic_store(xt->dst[q] + o, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        T g;
+        double unused;
+        if (peer_wait_sum<T, 1>(arena + o, true, R, slot_elems, xt, my_poison, state, limit, g, unused)) {
+            // SPEC 2.4: V <- mu V - lr g ; X <- X + V, g = the sum over ranks in rank order
+            const T vv = p.mu * vo - p.lr * g;
+            p.V[o] = vv;
+            p.X[o] = xo + vv;
         }
-        if (first && lane == 0) {
+    } else if (first && tid >= 128 && tid < 192) {
+        // the stress travels the same way, as a pair (hi, lo) behind the 3 * n_pad elements:
+        // one lane of a wave that has nothing else to do
+        const bool lane0 = tid == 128;
+        const int64_t n3 = 3 * p.n_pad;
+        if (lane0) {
             const double Sx = sh[0];
-            const T hi = (T)Sx, lo = (T)(Sx - (double)hi);
+            const T hi = (T)Sx;
+            const T lo = (T)(Sx - (double)hi);
             for (int q = 0; q < R; ++q) {
-                xt->dst[q][3 * p.n_pad] = hi;
-                xt->dst[q][3 * p.n_pad + 1] = lo;
+                __hip_atomic_store(xt->dst[q] + n3, peer_sendable(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(xt->dst[q] + n3 + 1, peer_sendable(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
-        // (one release per workgroup: it is a write-back of the XCD's L2)
-        if (lane < R)
-            __hip_atomic_store(xt->flag[lane] + item, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        // lanes [0, R): the flag of this workgroup from rank `lane`; [R, 2R): that rank's
-        // poison word; lane 2R: this rank's own status.  Relaxed system-scope loads (they go
-        // past the caches of this device), one acquire when the wait is over.
-        const unsigned long long *addr = lane < R ? my_flags + (int64_t)lane * n_items + item
-                                                  : my_poison + 8 * (lane < 2 * R ? lane - R : 0);
-        bool ok = false;
-        const long long t0 = wall_clock64();
-        for (;;) {
-            unsigned long long f = p.seq;
-            if (lane < 2 * R)
-                f = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            else if (lane == 2 * R)
-                f = (unsigned long long)__hip_atomic_load(&state->status, __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT);
-            const bool bad = (lane >= R && lane < 2 * R && f == kPeerPoison) || (lane == 2 * R && f != 0);
-            if (__ballot(bad) != 0) break;
-            const bool here = lane >= R || f >= p.seq;
-            if (__ballot(here) == __ballot(1)) { ok = true; break; }
-            if (__ballot(wall_clock64() - t0 > limit) != 0) break;   // wave-uniform exits only
-            __builtin_amdgcn_s_sleep(2);
+        T unused;
+        double Sx;
+        if (peer_wait_sum<T, 2>(arena + n3, lane0, R, slot_elems, xt, my_poison, state, limit, unused, Sx) && lane0) {
+            *p.stress_out = Sx;
+            __hip_atomic_store(&state->verdict, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (ok) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");           // system scope
-        } else {
-            if (lane < R)
-                __hip_atomic_store(xt->poison[lane], kPeerPoison, __ATOMIC_RELEASE,
-                                   __HIP_MEMORY_SCOPE_SYSTEM);
-            if (lane == 0)
-                __hip_atomic_store(&state->status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) go = ok ? 1 : 0;
-    }
-    __syncthreads();
-    if (!go) return;
-    // X <- X + (mu V - lr * sum over ranks, in rank order).  The arena is uncached memory read
-    // with system-scope loads, issued behind the barrier: not older than the flags.
-    if (sl == 0) {
-        T g = T(0);
-        for (int r0 = 0; r0 < R; r0 += 8) {
-            T v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                v[q] = r0 + q < R ? __hip_atomic_load(arena + (int64_t)(r0 + q) * slot_elems + o,
-                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                  : T(0);
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (r0 + q < R) g += v[q];
-        }
-        const T vv = p.mu * vo - p.lr * g;
-        p.V[o] = vv;
-        p.X[o] = xo + vv;
-    }
-    if (first && tid == 0) {
-        double Sx = 0.0;
-        const int64_t n3 = 3 * p.n_pad;
-        for (int r = 0; r < R; ++r)
-            Sx += (double)__hip_atomic_load(arena + (int64_t)r * slot_elems + n3, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_SYSTEM) +
-                  (double)__hip_atomic_load(arena + (int64_t)r * slot_elems + n3 + 1, __ATOMIC_RELAXED,
-                                            __HIP_MEMORY_SCOPE_SYSTEM);
-        *p.stress_out = Sx;
-        __hip_atomic_store(&state->verdict, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
