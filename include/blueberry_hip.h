@@ -224,19 +224,22 @@ BB_API int bb_comm_cache_clear(void);
  *   bb_solver_peer_set_timeout  change that limit (a short one for a trial run)
  *   bb_solver_peer_form     1 = the one-launch form below, 0 = the two launches above
  * One-launch form (the default with one rank per GPU): the unit of exchange is what one
- * workgroup of the reduce sums anyway, 128 gradient elements of one block.  The workgroup
- * stores them into its rank's slot on every peer, raises its OWN flag there (one word per
- * workgroup and source rank), waits for the same flag from every rank, adds the `world`
- * partials in rank order and updates its 128 coordinates: { grad, exchange } per iteration,
- * and nobody waits for any workgroup but the owners of the same 128 elements.  Every
+ * workgroup of the reduce sums anyway, 128 gradient elements of one block.  Each thread that
+ * holds a sum stores it into its rank's slot on every peer, reads the same element of every
+ * rank's slot in its own arena until all have ARRIVED, adds the `world` partials in rank
+ * order, updates its coordinate and marks the words it read as empty again: { grad, exchange }
+ * per iteration, no flags and no fences -- an empty slot word holds all-ones (a NaN that no
+ * arithmetic produces; a sum that should ever carry those bits is sent as the canonical NaN),
+ * a 4- or 8-byte store is seen whole or not at all, and nothing else is published with it.
+ * Nobody waits for any workgroup but the owners of the same elements.  Every
  * workgroup pushes before it waits and workgroups start in index order, so the lowest
  * unfinished one can always finish -- if each rank has its GPU to itself.  bb_solver_peer_connect
  * sees from the handles (PCI ids) whether ranks SHARE a GPU (a rehearsal) and then keeps the
  * two-launch form: waiting workgroups of one rank can keep another rank's sweep off the
  * device.  BB_PEER_FUSED=0|1 overrides, identically on every rank.
  * Failure.  Two-launch form: decided ONCE per iteration, by one wave, for the whole update:
- * X is advanced by a complete step or not at all.  One-launch form: every workgroup decides
- * for its 128 elements, so a rank that dies in the middle of an exchange can leave its
+ * X is advanced by a complete step or not at all.  One-launch form: every wave decides
+ * for its 64 elements, so a rank that dies in the middle of an exchange can leave its
  * peers with part of a step applied; when nothing of an exchange arrives (a rank that is
  * late, stalled or gone) no workgroup applies anything.  Either way the failed rank stops
  * pushing and leaves a poison word on every peer, so their waits fail at once as well -- no
