@@ -1500,13 +1500,19 @@ int bb_solver_peer_status(bb_solver *s, int *status) {
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     BB_HIP_CHECK(hipMemcpy(&st, s->d_peer_state, sizeof(st), hipMemcpyDeviceToHost));
     if (status) *status = st.status;
-    if (st.status != 0)
+    if (st.status != 0) {
+        const bool one = s->peer_fused && s->red_slices > 0;
         return bb::fail(BB_ERR_STATE,
-                        "peer exchange: a rank did not deliver its partial within the time limit "
-                        "(BB_PEER_TIMEOUT_MS), or reported its own failure; this rank's "
-                        "coordinates were left at its last completed step (" +
+                        std::string("peer exchange: a rank did not deliver its partial within the "
+                                    "time limit (BB_PEER_TIMEOUT_MS), or reported its own failure; ") +
+                            (one ? "the last exchange this rank completed whole was "
+                                 : "this rank's coordinates were left at its last completed step (") +
                             std::to_string(st.verdict) + " of " + std::to_string(s->peer_seq) +
-                            " exchanges) and every peer has been told to stop");
+                            (one ? " (the one after it may be applied in part: the coordinates of "
+                                   "this solver are not a result)"
+                                 : " exchanges)") +
+                            " and every peer has been told to stop");
+    }
     return BB_OK;
 }
 
