@@ -258,7 +258,7 @@ def _peer_engines(world, n, dtype, wish, x0, mu=0.0):
     return engs
 
 
-@pytest.mark.parametrize("form", ["one launch", "two launches"])
+@pytest.mark.parametrize("form", ["one launch", "two launches", "one launch, 8 slices"])
 @pytest.mark.parametrize("dtype,tol,world", [("float32", 1e-5, 2), ("float64", 1e-12, 2),
                                              ("float32", 1e-5, 3)])
 def test_peer_exchange_in_one_process(dtype, tol, world, form, monkeypatch):
@@ -267,6 +267,11 @@ def test_peer_exchange_in_one_process(dtype, tol, world, form, monkeypatch):
     exchange (include/blueberry_hip.h): reduce + push + wait + sum + update in one launch,
     workgroup by workgroup, and the two launches with one flag per rank."""
     monkeypatch.setenv("BB_PEER_TIMEOUT_MS", "5000")
+    if form.endswith("8 slices"):
+        # the kernel's other instantiation (1024 threads, lists in 8 slices), which problems
+        # of this size do not reach by themselves
+        monkeypatch.setenv("BB_REDUCE_SLICES", "8")
+        form = "one launch"
     monkeypatch.setenv("BB_PEER_FUSED", "1" if form == "one launch" else "0")
     from blueberry_amd.solver import HipEngine
     from tests import _oracle
