@@ -319,7 +319,9 @@ def test_peer_exchange_forms_agree_bit_for_bit_over_a_long_run(monkeypatch):
         monkeypatch.setenv("BB_PEER_FUSED", "1" if form == "one launch" else "0")
         engs = _peer_engines(world, n, "float32", w, x0, mu=0.3)
         assert engs[0].peer_form() == form
-        for chunk in (1, 199, 400):
+        # in turns and in small pieces: the ranks of ONE process share its host thread, and a
+        # rank whose launch queue is full would block the thread that feeds the ranks it waits for
+        for chunk in (1, 99) + (100,) * 5:
             for e in engs:
                 e.iterate_peer(chunk, 1.0 / (2 * n))
         got = []
