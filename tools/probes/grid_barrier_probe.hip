@@ -140,6 +140,56 @@ __global__ __launch_bounds__(256) void persistent_inband(const double *full, int
     }
 }
 
+// (e) the same protocol with X staged ONCE per workgroup: 1024 threads = 16 waves = 4 rows of
+// 4 waves, one workgroup per CU; all threads fetch X_k (agent-scope loads, retried while a
+// word is empty) into LDS, then the rows are swept from LDS.
+__global__ __launch_bounds__(1024) void persistent_staged(const double *full, int ld, int n, double *X3,
+                                                          long long stride, double lr, int iters) {
+    extern __shared__ double xs[];                 // 3 * ld doubles
+    __shared__ double red[16][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i = blockIdx.x * 4 + (wv >> 2), part = wv & 3;
+    const double empty = __longlong_as_double(-1ll);
+    for (int k = 0; k < iters; ++k) {
+        const double *Xin = X3 + (long long)(k % 3) * stride;
+        double *Xout = X3 + (long long)((k + 1) % 3) * stride, *Xold = X3 + (long long)((k + 2) % 3) * stride;
+        for (int w = tid; w < 3 * n; w += 1024) {
+            double v;
+            do v = __hip_atomic_load(Xin + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (empty_word(v));
+            xs[w] = v;
+        }
+        for (int w = 3 * n + tid; w < 3 * ld; w += 1024) xs[w] = 0.0;
+        __syncthreads();
+        double gx = 0, gy = 0, gz = 0, xi = 0, yi = 0, zi = 0;
+        if (i < n) {
+            xi = xs[3 * i]; yi = xs[3 * i + 1]; zi = xs[3 * i + 2];
+            for (int j = part * 64 + lane; j < ld; j += 256) {
+                const double d = full[(long long)i * ld + j];
+                const double dx = xi - xs[3 * j], dy = yi - xs[3 * j + 1], dz = zi - xs[3 * j + 2];
+                const double d2 = dx * dx + dy * dy + dz * dz + 1e-30;
+                const double rinv = rsqrt(d2), res = d > 0 ? d2 * rinv - d : 0.0, c = res * rinv;
+                gx += c * dx; gy += c * dy; gz += c * dz;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            gx += __shfl_down(gx, o, 64); gy += __shfl_down(gy, o, 64); gz += __shfl_down(gz, o, 64);
+        }
+        if (lane == 0) { red[wv][0] = gx; red[wv][1] = gy; red[wv][2] = gz; }
+        __syncthreads();
+        if (i < n && part == 0 && lane == 0) {
+            for (int p = 1; p < 4; ++p) { gx += red[wv + p][0]; gy += red[wv + p][1]; gz += red[wv + p][2]; }
+            for (int c = 0; c < 3; ++c)
+                __hip_atomic_store(Xold + 3 * i + c, empty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(Xout + 3 * i, xi - lr * 2 * gx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(Xout + 3 * i + 1, yi - lr * 2 * gy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(Xout + 3 * i + 2, zi - lr * 2 * gz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+}
+
 int main(int argc, char **argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 963, ld = (n + 127) / 128 * 128, iters = 2000;
     double *full, *Xa, *Xb;
@@ -212,6 +262,24 @@ int main(int argc, char **argv) {
         const double dd = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / iters;
         double xd[3];
         CK(hipMemcpy(xd, X3 + (size_t)(iters % 3) * ld * 3, 24, hipMemcpyDeviceToHost));
+        // (e): the same from X_0 with X staged in LDS, one 1024-thread workgroup per 4 rows
+        double ee = 0, xe[3] = {0, 0, 0};
+        if ((n + 3) / 4 <= cus) {
+            CK(hipFuncSetAttribute((const void *)persistent_staged, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ld * 8));
+            CK(hipMemset(X3, 0xff, (size_t)3 * ld * 3 * 8));
+            CK(hipMemcpy(X3, hx, (size_t)ld * 3 * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(persistent_staged, dim3((n + 3) / 4), dim3(1024), 3 * ld * 8, st, full, ld, n, X3, (long long)ld * 3, lr, 100);
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(tmp, X3 + (size_t)1 * ld * 3, (size_t)ld * 3 * 8, hipMemcpyDeviceToHost));
+            CK(hipMemset(X3, 0xff, (size_t)3 * ld * 3 * 8));
+            CK(hipMemcpy(X3, tmp, (size_t)ld * 3 * 8, hipMemcpyHostToDevice));
+            t0 = std::chrono::steady_clock::now();
+            hipLaunchKernelGGL(persistent_staged, dim3((n + 3) / 4), dim3(1024), 3 * ld * 8, st, full, ld, n, X3, (long long)ld * 3, lr, iters);
+            CK(hipStreamSynchronize(st));
+            ee = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / iters;
+            CK(hipMemcpy(xe, X3 + (size_t)(iters % 3) * ld * 3, 24, hipMemcpyDeviceToHost));
+        }
+        printf("rep %d: ... the same with X staged in LDS once per 1024-thread workgroup %.2f us (x0 %.6f)\n", rep, ee, xe[0]);
         free(tmp);
         CK(hipFree(X3));
         printf("rep %d: one launch per iteration %.2f us | one launch, grid barrier %.2f us | fences and atomics "
