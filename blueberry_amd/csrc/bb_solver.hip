@@ -1823,6 +1823,57 @@ BB_API int bb_solver_debug_grad_repeat(bb_solver *s, int times) {
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     return BB_OK;
 }
+// Diagnostic build only (-DBB_OVERLAP_PROBE rides on the trace builds): an UPPER BOUND of what
+// overlapping the reduce of iteration k with sweep k + 1 could save (lever (a)).
+// The two run as a software pipeline on two streams -- sweep k waits for reduce k - 1 (one
+// iteration stale: the coordinates it reads are not the ones the solver would use, timing
+// only), reduce k waits for sweep k -- so every iteration has the two cross-queue
+// dependencies the real thing would have and NONE of its in-kernel hand-off.  If this is not
+// faster than the plain loop, nothing built on it can be.
+BB_API int bb_solver_debug_overlap_bound(bb_solver *s, int iters, double lr, double *us_plain,
+                                         double *us_pipelined) {
+    BB_TRY(check_ready(s, "bb_solver_debug_overlap_bound"));
+    BB_REQUIRE(us_plain != nullptr && us_pipelined != nullptr && iters >= 2 && iters <= 100000,
+               "bb_solver_debug_overlap_bound: bad argument");
+    BB_REQUIRE(s->world == 1 && !s->row_owner, "bb_solver_debug_overlap_bound: one rank, sweep path");
+    BB_TRY(bb::enter_device(s->device));
+    hipStream_t main_st = s->stream, side = nullptr;
+    BB_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    hipEvent_t e_sweep[2], e_red[2];
+    for (int q = 0; q < 2; ++q) {
+        BB_HIP_CHECK(hipEventCreateWithFlags(&e_sweep[q], hipEventDisableTiming));
+        BB_HIP_CHECK(hipEventCreateWithFlags(&e_red[q], hipEventDisableTiming));
+    }
+    auto now = []() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
+    int rc = BB_OK;
+    for (int phase = 0; phase < 2 && rc == BB_OK; ++phase) {
+        for (int pass = 0; pass < 2 && rc == BB_OK; ++pass) {        // pass 0 warms up
+            const int n = pass == 0 ? std::max(20, iters / 4) : iters;
+            const double t0 = now();
+            for (int k = 0; k < n && rc == BB_OK; ++k) {
+                if (phase == 0) {
+                    rc = launch_grad(s);
+                    if (rc == BB_OK) rc = launch_reduce(s, kReduceApply, lr, s->d_stress_scalar);
+                } else {
+                    if (k > 0) (void)hipStreamWaitEvent(main_st, e_red[(k - 1) & 1], 0);
+                    rc = launch_grad(s);
+                    (void)hipEventRecord(e_sweep[k & 1], main_st);
+                    (void)hipStreamWaitEvent(side, e_sweep[k & 1], 0);
+                    s->stream = side;
+                    if (rc == BB_OK) rc = launch_reduce(s, kReduceApply, lr, s->d_stress_scalar);
+                    s->stream = main_st;
+                    (void)hipEventRecord(e_red[k & 1], side);
+                }
+            }
+            (void)hipStreamSynchronize(side);
+            (void)hipStreamSynchronize(main_st);
+            if (pass == 1) *(phase == 0 ? us_plain : us_pipelined) = (now() - t0) / n;
+        }
+    }
+    for (int q = 0; q < 2; ++q) { hipEventDestroy(e_sweep[q]); hipEventDestroy(e_red[q]); }
+    hipStreamDestroy(side);
+    return rc;
+}
 // Diagnostic build only: the stamps of the last stress_grad_kernel launch,
 // 8 x uint64 per wave {start, first unit done, last unit consumed, end, xcc<<32 | hw_id,
 // first load landed, window landed, coordinates landed}.
