@@ -81,7 +81,8 @@ def _assign_last_wins(matrix, rows, cols, vals):
 
 def _nan_to_num(a):
     """`numpy.nan_to_num` of a float64 view of `a` (pyx:102) -- without the copy and the
-    three passes when every value is finite already (10 M triples: 36 ms instead of 0.7 s)."""
+    three passes when every value is finite already (10 M triples: 36 ms instead of 0.7 s).
+    Host paths only: the device scatter applies nan_to_num to the values as it reads them."""
     a = numpy.asarray(a, dtype=numpy.float64)
     return a if numpy.isfinite(a).all() else numpy.nan_to_num(a)
 
@@ -102,7 +103,9 @@ class _DeviceMatrix(object):
         bin * resolution -- Rao's format -- it is the bins the scatter kernel saw times the
         resolution (no sort of 2n doubles on the host); otherwise numpy's own union1d."""
         import ctypes
-        t = _nan_to_num(triples)                                            # pyx:102
+        # numpy.nan_to_num (pyx:102) is applied by the scatter kernels to the values they read:
+        # no pass over the triples on the host
+        t = numpy.asarray(triples, dtype=numpy.float64)
         if t.ndim != 2 or t.shape[1] != 3:
             raise ValueError("triples must have shape (n, 3)")
         # C-ordered rows are read in place; the reference's own layout -- pandas hands it
@@ -127,7 +130,7 @@ class _DeviceMatrix(object):
         if on_grid.value:
             regions = numpy.flatnonzero(present).astype(numpy.float64) * float(int(resolution))
         else:
-            regions = numpy.union1d(t[:, 0], t[:, 1])
+            regions = numpy.union1d(_nan_to_num(t[:, 0]), _nan_to_num(t[:, 1]))
         return self, regions
 
     @classmethod
@@ -216,8 +219,7 @@ class ContactMap(object):
         self._KRexpected = numpy.atleast_1d(numpy.loadtxt(KR_EXP.format(celltype, chromosome, kb)))
         self.n_bins = int(self._KRnorm.shape[0])
         data = pandas.read_csv(self.filename, delimiter="\t", engine="c", dtype="float64",
-                               header=None).values
-        data = _nan_to_num(data)
+                               header=None).values               # nan_to_num: on the device
         self._host = self._view = None
         self._dev, self.regions = _DeviceMatrix.from_triples(data, self.resolution, self.n_bins,
                                                              self.device, want_regions=True)
@@ -373,7 +375,7 @@ class ContactMap(object):
         self = cls.__new__(cls)
         self.resolution, self.chromosome, self.celltype = int(resolution), chromosome, celltype
         self.device, self.filename = _pick_device(device), ""
-        data = _nan_to_num(triples)
+        data = numpy.asarray(triples, dtype=numpy.float64)         # nan_to_num: on the device
         self.n_bins = int(n_bins)
         self._host = self._view = None
         self._dev, self.regions = _DeviceMatrix.from_triples(data, self.resolution, self.n_bins,

@@ -640,7 +640,8 @@ class StructureSolver(object):
         balanced and O/E-normalised on the device as `ContactMap.normalize`
         would (pyx:166-169).  A bin pair that occurs more than once keeps its last
         count, as in the reference's scatter (pyx:115-116)."""
-        t = numpy.nan_to_num(numpy.asarray(triples, dtype=numpy.float64))       # pyx:102
+        from .datatypes import _nan_to_num
+        t = _nan_to_num(triples)          # pyx:102 (no copy when every value is finite)
         if t.ndim != 2 or t.shape[1] != 3:
             raise ValueError("triples must have shape (n, 3)")
         n = int(n_bins) + 1

@@ -152,6 +152,35 @@ def test_contactmap_scatter_duplicates_last_wins(oracle):
                              oracle.contactmap_scatter(t, res, n_bins))
 
 
+def test_contactmap_scatter_applies_nan_to_num_on_the_device(oracle):
+    """`numpy.nan_to_num` of the triples (datatypes.pyx:102) is done by the scatter kernels as
+    they read (no pass over 240 MB on the host): NaN and infinite COUNTS become 0 and
+    +-DBL_MAX, a NaN POSITION becomes position 0, in every memory layout; the `regions` of a
+    map built from such triples are numpy's union1d of the cleaned positions."""
+    rng = numpy.random.default_rng(13)
+    n_bins, res, n = 60, 5000, 4000
+    bi, bj = rng.integers(0, n_bins, n), rng.integers(0, n_bins, n)
+    t = numpy.stack([bi * float(res), bj * float(res), rng.random(n) * 50], 1)
+    t[rng.choice(n, 40, replace=False), 2] = numpy.nan
+    t[rng.choice(n, 40, replace=False), 2] = numpy.inf
+    t[rng.choice(n, 40, replace=False), 2] = -numpy.inf
+    t[rng.choice(n, 20, replace=False), 0] = numpy.nan
+    t[rng.choice(n, 20, replace=False), 1] = numpy.nan
+    want = oracle.contactmap_scatter(t, res, n_bins)
+    assert not numpy.isnan(want).any() and (numpy.abs(want) == numpy.finfo(float).max).any()
+    for arr in (t, numpy.asfortranarray(t), t[::1].copy(order="C")):
+        assert numpy.array_equal(bb.datatypes.scatter_triples(arr, res, n_bins), want)
+    cm = bb.ContactMap.from_triples(t, res, n_bins)
+    assert numpy.array_equal(cm.matrix, want)
+    clean = numpy.nan_to_num(t)
+    assert numpy.array_equal(cm.regions, numpy.union1d(clean[:, 0], clean[:, 1]))
+    # an infinite position is out of range after nan_to_num (1.8e308 / resolution), as on the host
+    t2 = t.copy()
+    t2[5, 0] = numpy.inf
+    with pytest.raises(ValueError, match="outside"):
+        bb.datatypes.scatter_triples(t2, res, n_bins)
+
+
 @pytest.mark.parametrize("k", [0, 1, 2])
 @pytest.mark.parametrize("tag", ["raw_t0", "raw_tmed", "norm_t0", "norm_tmed"])
 def test_contactmap_filter_golden_bit_exact(k, tag):
