@@ -85,7 +85,11 @@ struct Lay<double, true> {
 template <>
 struct Lay<double, false> {
     static constexpr int LPR = 1, VW = 128, RPU = 8;
-    static constexpr int MIN_WG = 4;
+    // <= 256 VGPRs.  This shape only ever runs one workgroup of 4 waves per CU (at most 4096
+    // bins: fewer than 65k units, waves_per_cu() = 4), so a cap of 128 registers bought no
+    // occupancy and, from round 3 on, cost a 20-byte scratch spill in the stress sweep
+    // (tests/test_host.py::test_no_product_kernel_spills guards against the next one).
+    static constexpr int MIN_WG = 2;
     static constexpr bool SCALAR_XROW = false;  // 24 doubles x 2 would not fit the SGPR file:
                                                 // one per-lane load + v_readlane instead
 };

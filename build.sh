@@ -12,10 +12,4 @@ SRC="blueberry_amd/csrc/bb_api.cpp blueberry_amd/csrc/bb_comm.cpp blueberry_amd/
     -Iinclude -Iblueberry_amd/csrc ${BB_EXTRA_FLAGS:-} \
     -o blueberry_amd/libblueberry_hip.so $SRC -ldl
 make -s -C oracle
-# diagnostic / ablation variants that exist in this tree follow the product sources
-for f in blueberry_amd/libabl_*.flags; do
-    [ -e "$f" ] || continue
-    n=$(basename "$f" .flags); n=${n#libabl_}
-    tools/build_variant.sh "$n" $(cat "$f") > /dev/null
-done
 echo "built blueberry_amd/libblueberry_hip.so and oracle/libbb_oracle.so"

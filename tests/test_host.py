@@ -424,3 +424,48 @@ def test_entry_loops_without_python_loops_keep_last_wins():
     for m1, m2, _, p, _q in fm.map:
         want[int((m1 - res / 2) / res), int((m2 - res / 2) / res)] = p
     assert numpy.array_equal(got, want)
+
+
+def _kernel_metadata(so_path):
+    """{kernel name: {vgpr, sgpr, scratch}} from the gfx950 code object embedded in a
+    built .so (llvm-readelf --notes of the unbundled .hip_fatbin).  No GPU needed."""
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "k.co")
+        subprocess.check_call([llvm + "/llvm-objcopy", "-O", "binary",
+                               "--only-section=.hip_fatbin", so_path, fat])
+        subprocess.check_call([llvm + "/clang-offload-bundler", "--type=o",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                               "--input=" + fat, "--output=" + co, "--unbundle"])
+        notes = subprocess.check_output([llvm + "/llvm-readelf", "--notes", co], text=True)
+    out = {}
+    for m in re.finditer(r"\.name:\s+(\S+).*?(?=\.name:|\Z)", notes, re.S):
+        blk = m.group(0)
+        if ".vgpr_count" not in blk:
+            continue
+        g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))
+        out[m.group(1)] = {"vgpr": g("vgpr_count"), "sgpr": g("sgpr_count"),
+                           "scratch": g("private_segment_fixed_size")}
+    return out
+
+
+def test_no_product_kernel_spills():
+    """round 3 shipped a 20-byte scratch spill in the narrow fp64 sweep and
+    nothing noticed.  Every kernel of the product library must compile without scratch
+    (private_segment_fixed_size = 0 in the code object's metadata), and the dominant
+    kernels within the register budget their launch bounds assume."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("no LLVM binutils here")
+    meta = _kernel_metadata(_lib.LIB_PATH)
+    assert len(meta) > 40, "kernel metadata not found in %s" % _lib.LIB_PATH
+    spills = {k: v["scratch"] for k, v in meta.items() if v["scratch"] > 0}
+    assert not spills, "kernels with scratch: %r" % spills
+    sweeps = {k: v for k, v in meta.items() if "stress_grad_kernel" in k}
+    assert len(sweeps) >= 12
+    for k, v in sweeps.items():
+        if "IfLb" in k:                       # fp32: two workgroups of 8 waves per CU
+            assert v["vgpr"] <= 128, (k, v)
+        else:                                 # fp64: two waves per SIMD
+            assert v["vgpr"] <= 256, (k, v)

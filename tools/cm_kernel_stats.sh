@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}; export TMPDIR=/tmp
 out=$R/gpurun_out/cm_kernel_stats.txt; : > $out
 for v in product "$@"; do
   O=$R/gpurun_out/cmstats_$v; rm -rf $O; mkdir -p $O
-  lib=$R/blueberry_amd/libblueberry_hip.so; [ $v = product ] || lib=$R/blueberry_amd/libabl_$v.so
+  lib=$R/blueberry_amd/libblueberry_hip.so; [ $v = product ] || lib=$R/tools/variants/libabl_$v.so
   BB_LIB=$lib rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/tools/bench_contactmap.py > $O.log 2>&1 || { tail -3 $O.log; continue; }
   echo "== $v" >> $out
   f=$(ls $O/*/*kernel_stats.csv | head -1)

@@ -7,6 +7,6 @@ run() { echo -n "$1 bins $2: " >> $out; shift; n=$1; shift
    | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('step_ms', round(d['ms_per_step'],4), 'kernel_ms', round(r['kernel_ms'],4), 'frac', round(r['frac'],3), 'Gpair/s', round(d['value'],1))" >> $out 2>&1; }
 for rep in 1 2 3; do for n in 20000 40000; do
   run mfma $n BB_X=1
-  run generic $n BB_LIB=$PWD/blueberry_amd/libabl_F64GEN.so BB_DEFER_ROWS=0
+  run generic $n BB_LIB=$PWD/tools/variants/libabl_F64GEN.so BB_DEFER_ROWS=0
 done; done
 sort -k3,3n -k1,1 $out

@@ -1,7 +1,7 @@
 """VERDICT r2 #1 lever (a), bounded from above: the reduce of iteration k and sweep k + 1 as a
 software pipeline on two streams (one iteration stale, timing only) against the plain loop.
 Needs a trace build (tools/build_variant.sh UTRACE -DBB_UNIT_TRACE); run with
-BB_LIB=$PWD/blueberry_amd/libabl_UTRACE.so python tools/overlap_bound.py [N ...]"""
+BB_LIB=$PWD/tools/variants/libabl_UTRACE.so python tools/overlap_bound.py [N ...]"""
 import ctypes, os, sys
 import numpy
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,7 +1,7 @@
 """Unit-by-unit time line of one stress_grad_kernel launch (diagnostic build).
 
     tools/build_variant.sh UTRACE -DBB_UNIT_TRACE
-    BB_LIB=$PWD/blueberry_amd/libabl_UTRACE.so python tools/unit_trace.py [bins ...]
+    BB_LIB=$PWD/tools/variants/libabl_UTRACE.so python tools/unit_trace.py [bins ...]
 
 Every wave keeps the time at the top of each of its units in LDS (one s_memrealtime and one
 ds_write per unit; the unit loop is the product's: same wait counts, nothing peeled) and

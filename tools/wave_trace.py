@@ -1,6 +1,6 @@
 """Where a stress_grad_kernel launch spends its time, wave by wave (diagnostic build).
 
-    BB_LIB=$PWD/blueberry_amd/libabl_TRACE.so python tools/wave_trace.py [bins ...]
+    BB_LIB=$PWD/tools/variants/libabl_TRACE.so python tools/wave_trace.py [bins ...]
 
 libabl_TRACE.so = the product sources + -DBB_WAVE_TRACE (bb_ablate.h): every wave leaves
 eight stamps (10-ns ticks): start, first unit done, last unit consumed, end, where it ran,

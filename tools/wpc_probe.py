@@ -16,5 +16,5 @@ for wpc in (None, "1", "2"):
     env = dict(os.environ)
     if wpc: env["BB_WAVES_PER_CU"] = wpc
     subprocess.run([sys.executable, "-c", code], env=env)
-env = dict(os.environ, BB_LIB=os.getcwd() + "/blueberry_amd/libabl_OLD.so")
+env = dict(os.environ, BB_LIB=os.getcwd() + "/tools/variants/libabl_OLD.so")
 print("OLD:"); subprocess.run([sys.executable, "-c", code], env=env)
