@@ -48,10 +48,23 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--bins", type=int, default=50000)
+    ap.add_argument("--bins", type=int, default=None,
+                    help="bins of the map (default: 50000 dense, 309568 genome10kb; another "
+                         "value rescales the genome's chromosome proportions)")
+    ap.add_argument("--workload", default="dense", choices=["dense", "genome10kb"],
+                    help="dense: BASELINE's headline, a dense N-bin wish matrix (configs 2-4). "
+                         "genome10kb: BASELINE config 5, the whole hg19 genome at 10 kb bins "
+                         "(N = 309,568) as blocked-sparse tiles -- every chromosome's own block "
+                         "plus a band of --band-bins around the diagonal; pairs = stored pairs")
+    ap.add_argument("--band-bins", type=int, default=1000,
+                    help="genome10kb: tiles holding a pair of bins at most this far apart are "
+                         "kept across chromosome borders too (1000 bins = 10 Mb = the reference's "
+                         "HIGH_FITHIC_CUTOFF, blueberry/utils.py:25)")
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-bins", type=int, default=10000)
+    ap.add_argument("--cpu-bins", type=int, default=None,
+                    help="bins of the cpu_baseline sample (default 10000 dense; genome10kb: "
+                         "61914 = the same genome at 50 kb bins)")
     ap.add_argument("--cpu-iters", type=int, default=100)
     ap.add_argument("--converge-steps", type=int, default=60)
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -76,7 +89,15 @@ def parse():
     ap.add_argument("--reps", type=int, default=5,
                     help="further repetitions of the --steps block after the timed one, for "
                          "the spread of ms_per_step (0 = none)")
-    return ap.parse_args()
+    ap.add_argument("--check-every", type=int, default=5,
+                    help="measured time-to-converged-stress legs: the stress history is read "
+                         "back (one sync + D2H) every this many steps, as fit(tol=...) does")
+    a = ap.parse_args()
+    if a.bins is None:
+        a.bins = 50000 if a.workload == "dense" else 309568
+    if a.cpu_bins is None:
+        a.cpu_bins = 10000 if a.workload == "dense" else 61914
+    return a
 
 
 def self_launch(a):
@@ -181,10 +202,55 @@ def cpu_baseline(n, iters):
     return out
 
 
+def cpu_baseline_genome(n, band_bins, iters):
+    """The config-5 workload on the host cores: the SAME block structure (hg19 chromosome
+    proportions, one block per chromosome + a band) at a bounded size -- by default the
+    genome at 50 kb bins, N = 61,914, band 10 Mb -- through the oracle's tile-list loop
+    (oracle/bb_oracle_mt.c bbo_solve_gen_mt: wish distances formed on the fly from the
+    generating walk, only stored pairs are visited and counted).  kind = "port"."""
+    from tests import _oracle
+    from blueberry_amd.solver import max_degree, tiles_from_blocks
+    from blueberry_amd.utils import genome_boundaries
+    tiles, pairs = tiles_from_blocks(n, genome_boundaries(n), band_bins, "float32")
+    xs = random_walk(n)
+    x0 = xs + 0.5 * numpy.random.default_rng(1).standard_normal(xs.shape)
+    lr = 1.0 / (2 * max_degree(n, tiles, "float32"))
+    what = ("hg19 chromosome blocks + %d-bin band at N=%d (%d tiles of 512, %d stored pairs)"
+            % (band_bins, n, len(tiles[0]), pairs))
+    t0 = time.perf_counter()
+    _oracle.solve_gen_mt(xs, x0, 1, lr, 1, tiles=tiles, f64=False)
+    per1 = time.perf_counter() - t0
+    it1 = int(min(max(3.0 / per1, 1), iters))
+    t0 = time.perf_counter()
+    _oracle.solve_gen_mt(xs, x0, it1, lr, 1, tiles=tiles, f64=False)
+    dt1 = time.perf_counter() - t0
+    one = pairs * it1 / dt1 / 1e9
+    out = {"value": one, "unit": "Gpair-updates/s", "cores": 1, "kind": "port",
+           "sample": "oracle bbo_solve_gen_mt, %s, %d iterations, %.1f s, gcc -O2, 1 thread"
+                     % (what, it1, dt1)}
+    cores = host_cores()
+    if cores > 1:
+        _oracle.solve_gen_mt(xs, x0, 2, lr, cores, tiles=tiles, f64=False)
+        t0 = time.perf_counter()
+        _oracle.solve_gen_mt(xs, x0, 4, lr, cores, tiles=tiles, f64=False)
+        per_iter = (time.perf_counter() - t0) / 4
+        itm = int(min(max(8.0 / per_iter, 4), 100 * iters))
+        t0 = time.perf_counter()
+        _oracle.solve_gen_mt(xs, x0, itm, lr, cores, tiles=tiles, f64=False)
+        dtm = time.perf_counter() - t0
+        out = {"value": pairs * itm / dtm / 1e9, "unit": "Gpair-updates/s", "cores": cores,
+               "kind": "port",
+               "sample": "oracle bbo_solve_gen_mt (OpenMP, tiles dealt cyclically), %s, "
+                         "%d iterations, %.1f s, gcc -O2 -fopenmp, %d threads"
+                         % (what, itm, dtm, cores),
+               "single_core": {"value": one, "sample": out["sample"]}}
+    return out
+
+
 PMC_TABLE = "profiles/pmc_latest.json"
 
 
-def pmc_traffic(n_bins, dtype, world):
+def pmc_traffic(n_bins, dtype, world, workload="dense"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC
     passes on this configuration (profiles/pmc_latest.json: one entry per problem
     size, written by tools/tools_pmc.sh), or None.  It is replayed from the profile,
@@ -194,7 +260,8 @@ def pmc_traffic(n_bins, dtype, world):
         with open(p) as fh:
             d = json.load(fh)
         for e in d.get("entries", [d]):
-            if e.get("bins") == n_bins and e.get("dtype") == dtype and e.get("gpus", 1) == world:
+            if (e.get("bins") == n_bins and e.get("dtype") == dtype and e.get("gpus", 1) == world
+                    and e.get("workload", "dense") == workload):
                 return e.get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
@@ -259,8 +326,20 @@ def main():
     n = a.bins if a.scaling == "strong" else int(round(a.bins * world ** 0.5))
     xs = random_walk(n, 0)
     x0 = xs + 0.5 * numpy.random.default_rng(1).standard_normal(xs.shape)
+    tiles = None
+    pairs = n * (n - 1) // 2
     lr = 1.0 / (2 * n)
-    eng = HipEngine(n, a.dtype, rank=rank, world=world, device=local_rank)
+    if a.workload == "genome10kb":
+        # BASELINE config 5: the dense (n_bins+1)^2 float64 matrix of the reference
+        # (blueberry/datatypes.pyx:99) would be 720 GB; the tiles a Hi-C map populates -- each
+        # chromosome's own block and a band along the diagonal -- are 10.5 GB in fp32
+        from blueberry_amd.solver import max_degree, tiles_from_blocks
+        from blueberry_amd.utils import genome_boundaries
+        if a.scaling != "strong":
+            raise SystemExit("bench.py: --workload genome10kb is a fixed map (strong scaling)")
+        tiles, pairs = tiles_from_blocks(n, genome_boundaries(n), a.band_bins, a.dtype)
+        lr = 1.0 / (2 * max_degree(n, tiles, a.dtype))
+    eng = HipEngine(n, a.dtype, rank=rank, world=world, device=local_rank, tiles=tiles)
     eng.set_wish_from_coords(xs)          # delta_ij = |x*_i - x*_j| generated in HBM
     eng.set_coords(x0)
     if use_dist:
@@ -313,12 +392,55 @@ def main():
         return {"iterations": None, "ms": None, "stress_ratio": float(h2[-1] / h2[0]),
                 "momentum": mu, "lr_times_2N": relax}
 
-    conv = conv_mu = conv_relaxed = None
+    def converge_measured(mu, relax=1.0, spectral=False):
+        """The same leg TIMED END TO END the way the product stops early
+        (StructureSolver.fit(tol=...), blueberry_amd/solver.py): --check-every steps are
+        enqueued, the stress history is read back (a sync + a D2H), and the loop ends at the
+        first read that shows S_k <= 1e-3 S_0.  The wall clock includes every read-back and,
+        with `spectral`, the classical-MDS start computed on the device; S_0 is the stress of
+        the noisy start X0 either way."""
+        eng.set_timing(False)
+        eng.set_coords(x0)
+        eng.set_momentum(mu)
+        s0 = None
+        if spectral:
+            s0 = eng.stress()                    # S(X0): the yardstick, before the clock starts
+        fence()
+        t1 = time.perf_counter()
+        if spectral:
+            eng.spectral_init_device(40, numpy.random.default_rng(0).standard_normal((n, 3)))
+        done, reads, hit = 0, 0, None
+        while done < a.converge_steps:
+            k = min(a.check_every, a.converge_steps - done)
+            steps(k, relax * lr)
+            done += k
+            h2 = eng.stress_history()            # synchronises: the read-back is in the figure
+            reads += 1
+            if s0 is None:
+                s0 = h2[0]
+            if h2[-1] <= 1e-3 * s0:
+                hit = int(numpy.nonzero(h2 <= 1e-3 * s0)[0][0])
+                break
+        fence()
+        dtc = time.perf_counter() - t1
+        return {"measured_ms": dtc * 1e3 if hit is not None else None, "iterations_run": done,
+                "first_iteration_below": hit, "stress_reads": reads,
+                "check_every": a.check_every, "momentum": mu, "lr_times_2N": relax,
+                "start": "spectral (40 block power iterations on the device, inside the clock)"
+                         if spectral else "noisy X0"}
+
+    conv = conv_mu = conv_relaxed = conv_spectral = None
     if a.converge_steps > 0:
         conv = converge_leg(0.0)             # the plain step the throughput figure is timed on
         conv_mu = converge_leg(a.momentum)   # heavy-ball, SPEC 2.4
         # over-relaxed majorisation step lr = omega / 2N (omega < 2) + heavy-ball, SPEC 2.4
         conv_relaxed = converge_leg(a.relax_momentum, a.relax)
+        # ... and the same three with the early stop really running (wall clock incl. read-backs)
+        conv.update(converge_measured(0.0))
+        conv_mu.update(converge_measured(a.momentum))
+        conv_relaxed.update(converge_measured(a.relax_momentum, a.relax))
+        if world == 1 and not use_dist:
+            conv_spectral = converge_measured(0.0, spectral=True)
         eng.set_momentum(0.0)
     read_ms = eng.stream_read_ms(10) if a.dtype == "float32" else None
     eng.set_coords(x0)                       # the timed block starts where the legs did
@@ -416,7 +538,6 @@ def main():
     eng.close()
     if rank == 0:
         es = 4 if a.dtype == "float32" else 8
-        pairs = n * (n - 1) // 2
         value = pairs * a.steps / dt / 1e9
         # dominant kernel: algorithmic bytes this rank's launch streams / its duration
         alg_bytes = pairs * es / float(world)
@@ -427,7 +548,10 @@ def main():
                   "stay in L2 / the Infinity Cache -- launch-bound, the HBM roofline does not apply"
                   % (tname, waves_per_row))
         out = {
-            "metric": "Gpair-updates/s per stress iteration, N=50k" if n == 50000 else
+            "metric": ("Gpair-updates/s per stress iteration, N=%d blocked-sparse tiles "
+                       "(whole genome at 10 kb bins, stored pairs)" % n)
+                      if tiles is not None else
+                      "Gpair-updates/s per stress iteration, N=50k" if n == 50000 else
                       "Gpair-updates/s per stress iteration, N=%d" % n,
             "value": value,
             "unit": "Gpair-updates/s",
@@ -443,10 +567,21 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if a.dtype == "float32" else "f64",
             "data": "synthetic",
-            "config": {"workload": "dense %d-bin wish-distance matrix from a seeded 3-D random "
+            "config": {"workload": ("genome10kb: %d bins = hg19 at 10 kb, blocked-sparse 512 x 512 "
+                                    "tiles (each chromosome's own block + a %d-bin band: %d of %d "
+                                    "upper tiles), wish distances from a seeded 3-D random walk "
+                                    "generated in HBM, %s; one stress+gradient+update iteration "
+                                    "over the stored pairs per step (BASELINE config 5)"
+                                    % (n, a.band_bins, len(tiles[0]),
+                                       (-(-n // 512)) * (-(-n // 512) + 1) // 2, a.dtype))
+                                   if tiles is not None else
+                                   "dense %d-bin wish-distance matrix from a seeded 3-D random "
                                    "walk, upper triangle packed in HBM, %s; one stress+gradient+"
                                    "update iteration per step" % (n, a.dtype),
                        "bins": n, "pairs_per_step": pairs,
+                       "stored_pairs": pairs if tiles is not None else None,
+                       "stored_tiles": len(tiles[0]) if tiles is not None else None,
+                       "lr": lr,
                        "parallelism": "unit-range sharding x%d + all-reduce(3*n_pad+2) via %s"
                                       % (world, eng_comm) if world > 1 else "1 gpu",
                        "exchange": eng._comm_state, "exchange_trial": comm_trial,
@@ -454,11 +589,11 @@ def main():
                        "rccl_reported_world": rccl_world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(n, a.dtype, world),
+                         "traffic": pmc_traffic(n, a.dtype, world, a.workload),
                          # counters need rocprofv3 passes of their own: replayed, not measured here
                          "traffic_source": ("%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                             "this configuration, replayed)" % PMC_TABLE)
-                         if pmc_traffic(n, a.dtype, world) is not None else None,
+                         if pmc_traffic(n, a.dtype, world, a.workload) is not None else None,
                          "kernel": kernel,
                          "kernel_ms": tim["grad_ms"], "reduce_update_ms": tim["reduce_ms"],
                          # two events back to back on this stream: an upper bound of what an
@@ -484,11 +619,14 @@ def main():
             "time_to_stress_1e-3": conv,
             "time_to_stress_1e-3_momentum": conv_mu,
             "time_to_stress_1e-3_relaxed": conv_relaxed,
+            "time_to_stress_1e-3_spectral_start": conv_spectral,
             "reference_parity": "N/A - path absent in reference; parity is against this "
                                 "repo's CPU oracle (tests/)",
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_bins, a.cpu_iters)
+            out["cpu_baseline"] = (cpu_baseline(a.cpu_bins, a.cpu_iters) if tiles is None else
+                                   cpu_baseline_genome(a.cpu_bins, max(1, a.band_bins * a.cpu_bins // n),
+                                                       a.cpu_iters))
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -408,6 +408,52 @@ def tiles_from_entries(n_bins, rows, cols, dtype):
     return (key % nb).astype(numpy.int32), (key // nb).astype(numpy.int32)
 
 
+def tiles_from_blocks(n_bins, boundaries, band_bins, dtype):
+    """Tile list of a block-sparse genome-wide map (BASELINE config 5; SURVEY.md 8(d):
+    a tile is kept "when genomic separation <= band or the tile has any c > 0"): every
+    tile that holds a pair of bins of ONE block of `boundaries` -- a chromosome's own
+    contacts, where a Hi-C map is populated -- plus every tile that holds a pair of bins
+    at most `band_bins` apart whatever the block.  `boundaries` = ascending bin offsets
+    [0, ..., n_bins] (blueberry_amd.utils.genome_boundaries).  Replaces the dense
+    `(n_bins+1)**2` float64 matrix of the reference (`blueberry/datatypes.pyx:99`: 720 GB
+    at 10 kb) for whole-genome maps.  Returns (tile_I, tile_J) in device order and the
+    number of stored pairs i < j < n_bins inside those tiles."""
+    vw = layout_info(n_bins, dtype)["vw"]
+    n = int(n_bins)
+    b = numpy.asarray(boundaries, dtype=numpy.int64)
+    if b.ndim != 1 or b.size < 2 or b[0] != 0 or b[-1] != n or (numpy.diff(b) < 0).any():
+        raise ValueError("boundaries must ascend from 0 to n_bins")
+    nb = (n + vw - 1) // vw
+    first = numpy.arange(nb, dtype=numpy.int64) * vw
+    last = numpy.minimum(first + vw, n) - 1
+    blk_lo = numpy.searchsorted(b, first, side="right") - 1     # block of a tile's first bin
+    blk_hi = numpy.searchsorted(b, last, side="right") - 1      # ... and of its last bin
+    J, I = numpy.meshgrid(numpy.arange(nb), numpy.arange(nb))
+    upper = I <= J
+    same_block = blk_hi[I] >= blk_lo[J]           # I <= J and blocks are contiguous runs
+    near = (J - I - 1) * vw + 1 <= int(band_bins)   # closest pair of bins of the two tiles
+    sel = upper & (same_block | near)
+    ti, tj = I[sel], J[sel]
+    order = numpy.lexsort((ti, tj))
+    ti, tj = ti[order].astype(numpy.int32), tj[order].astype(numpy.int32)
+    rows = numpy.minimum(vw, n - ti.astype(numpy.int64) * vw)
+    cols = numpy.minimum(vw, n - tj.astype(numpy.int64) * vw)
+    pairs = int(numpy.where(ti == tj, rows * (rows - 1) // 2, rows * cols).sum())
+    return (ti, tj), pairs
+
+
+def max_degree(n_bins, tiles, dtype):
+    """Upper bound on the number of stored partners of any bin under a tile list: the step
+    1 / (2 * max_degree) is inside the majorisation bound (docs/SPEC.md 2.4), as 1 / (2 N)
+    is for a dense map."""
+    vw = layout_info(n_bins, dtype)["vw"]
+    nb = (int(n_bins) + vw - 1) // vw
+    ti, tj = numpy.asarray(tiles[0]), numpy.asarray(tiles[1])
+    deg = numpy.bincount(ti, minlength=nb) + numpy.bincount(tj, minlength=nb)
+    deg -= numpy.bincount(ti[ti == tj], minlength=nb)             # a diagonal tile counts once
+    return int(min(int(n_bins), deg.max() * vw))
+
+
 def allreduce_exchange(t):
     """Sum a device-resident exchange tensor over all ranks, in place: one
     all-reduce of 3*n_pad+2 elements (backend nccl = RCCL, over xGMI)."""

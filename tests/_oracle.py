@@ -152,10 +152,8 @@ def load():
 _cached_mt = None
 
 
-def solve_mt(wish, X0, iters, lr, threads, f64=True):
-    """bbo_solve on `threads` host cores (oracle/bb_oracle_mt.c, OpenMP): the
-    multi-core cpu_baseline of bench.py.  Raises OSError if it cannot be built or
-    loaded (no libgomp): callers fall back to the scalar oracle."""
+def _load_mt():
+    """oracle/libbb_oracle_mt.so (OpenMP); OSError / CalledProcessError without libgomp."""
     global _cached_mt
     if _cached_mt is None:
         so = os.path.join(ORACLE_DIR, "libbb_oracle_mt.so")
@@ -166,14 +164,76 @@ def solve_mt(wish, X0, iters, lr, threads, f64=True):
         lib.bbo_solve_mt.restype = ctypes.c_int
         lib.bbo_solve_mt.argtypes = [p_dbl, c_long, c_long, p_dbl, c_long, c_dbl, ctypes.c_int,
                                      p_dbl, ctypes.c_int]
+        lib.bbo_solve_momentum_mt.restype = ctypes.c_int
+        lib.bbo_solve_momentum_mt.argtypes = [p_dbl, c_long, c_long, p_dbl, c_long, c_dbl, c_dbl,
+                                              ctypes.c_int, p_dbl, ctypes.c_int]
+        lib.bbo_solve_gen_mt.restype = ctypes.c_int
+        lib.bbo_solve_gen_mt.argtypes = [p_dbl, c_long, p_i32, p_i32, c_long, c_long, p_dbl, c_long,
+                                         c_dbl, c_dbl, ctypes.c_int, ctypes.c_int, c_dbl, p_dbl,
+                                         ctypes.c_int]
         _cached_mt = lib
+    return _cached_mt
+
+
+def solve_mt(wish, X0, iters, lr, threads, f64=True):
+    """bbo_solve on `threads` host cores (oracle/bb_oracle_mt.c, OpenMP): the
+    multi-core cpu_baseline of bench.py.  Raises OSError if it cannot be built or
+    loaded (no libgomp): callers fall back to the scalar oracle."""
+    lib = _load_mt()
     w = numpy.ascontiguousarray(wish, dtype=numpy.float64)
     X = numpy.ascontiguousarray(X0, dtype=numpy.float64).copy()
     hist = numpy.zeros(iters)
-    rc = _cached_mt.bbo_solve_mt(_p(w), w.shape[0], w.shape[1], _p(X), int(iters), float(lr),
+    rc = lib.bbo_solve_mt(_p(w), w.shape[0], w.shape[1], _p(X), int(iters), float(lr),
                                  1 if f64 else 0, _p(hist), int(threads))
     if rc != 0:
         raise MemoryError("bbo_solve_mt: out of memory")
+    return X, hist
+
+
+def solve_momentum_mt(wish, X0, iters, lr, mu, threads, f64=True):
+    """bbo_solve_momentum on `threads` host cores (mu = 0: plain steps)."""
+    lib = _load_mt()
+    w = numpy.ascontiguousarray(wish, dtype=numpy.float64)
+    X = numpy.ascontiguousarray(X0, dtype=numpy.float64).copy()
+    hist = numpy.zeros(iters)
+    rc = lib.bbo_solve_momentum_mt(_p(w), w.shape[0], w.shape[1], _p(X), int(iters), float(lr),
+                                   float(mu), 1 if f64 else 0, _p(hist), int(threads))
+    if rc != 0:
+        raise MemoryError("bbo_solve_momentum_mt: out of memory")
+    return X, hist
+
+
+def dense_tiles(n, vw=512):
+    """Tile list of the dense upper triangle, device order (J, then I ascending)."""
+    nb = -(-int(n) // vw)
+    tj, ti = numpy.meshgrid(numpy.arange(nb), numpy.arange(nb))
+    sel = ti <= tj
+    order = numpy.lexsort((ti[sel], tj[sel]))
+    return ti[sel][order].astype(numpy.int32), tj[sel][order].astype(numpy.int32)
+
+
+def solve_gen_mt(xstar, X0, iters, lr, threads, tiles=None, vw=512, mu=0.0, f64=True,
+                 delta_f32=None):
+    """The solver loop with delta_ij = |x*_i - x*_j| formed on the fly over a tile list
+    (None: the dense upper triangle) -- no matrix in memory, so N = 50,000 dense and
+    BASELINE config 5 (N = 309,568 block-sparse) run on the host.  delta_f32 (default:
+    not f64) rounds delta to float exactly as the device's fp32 pack does."""
+    lib = _load_mt()
+    xs = numpy.ascontiguousarray(xstar, dtype=numpy.float64)
+    X = numpy.ascontiguousarray(X0, dtype=numpy.float64).copy()
+    n = xs.shape[0]
+    ti, tj = dense_tiles(n, vw) if tiles is None else tiles
+    ti = numpy.ascontiguousarray(ti, dtype=numpy.int32)
+    tj = numpy.ascontiguousarray(tj, dtype=numpy.int32)
+    if delta_f32 is None:
+        delta_f32 = not f64
+    hist = numpy.zeros(iters)
+    rc = lib.bbo_solve_gen_mt(_p(xs), n, ti.ctypes.data_as(p_i32), tj.ctypes.data_as(p_i32),
+                              ti.shape[0], int(vw), _p(X), int(iters), float(lr), float(mu),
+                              1 if f64 else 0, 1 if delta_f32 else 0,
+                              1e-30 if delta_f32 else 1e-290, _p(hist), int(threads))
+    if rc != 0:
+        raise MemoryError("bbo_solve_gen_mt: out of memory")
     return X, hist
 
 

@@ -193,6 +193,63 @@ def test_multicore_baseline_equals_scalar_oracle(oracle, threads):
     assert numpy.array_equal(Xt, Xt2) and numpy.array_equal(ht, ht2)   # reproducible
 
 
+@pytest.mark.parametrize("threads", [1, 4])
+def test_multicore_momentum_twin_equals_scalar_oracle(oracle, threads):
+    """bbo_solve_momentum_mt (the K = 20 twin of the depth-parity GPU tests) runs
+    bbo_solve_momentum's iteration; mu = 0 is bbo_solve_mt bit for bit."""
+    n = 193
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    w[7, 90] = w[90, 7] = 0.0
+    x0 = _oracle.noisy_init(xs)
+    lr = 1.0 / (2 * n)
+    X1, h1 = oracle.solve_momentum(w, x0, 20, lr, 0.5)
+    Xt, ht = _oracle.solve_momentum_mt(w, x0, 20, lr, 0.5, threads)
+    assert numpy.abs(Xt - X1).max() < 1e-11 * numpy.abs(X1).max()
+    assert numpy.abs(ht / h1 - 1).max() < 1e-11
+    a = _oracle.solve_mt(w, x0, 7, lr, threads)
+    b = _oracle.solve_momentum_mt(w, x0, 7, lr, 0.0, threads)
+    assert numpy.array_equal(a[0], b[0]) and numpy.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("f64", [True, False])
+def test_generated_delta_oracle_equals_scalar_oracle_on_the_explicit_matrix(oracle, f64):
+    """bbo_solve_gen_mt forms delta_ij = |x*_i - x*_j| on the fly (rounded to float when
+    the device would store it as float) over a tile list: on a small map it must equal
+    the scalar bbo_solve run on the explicit matrix with the same rounding -- dense, and
+    block-sparse (absent tiles = zeros in the matrix)."""
+    n, vw, k = 300, 64, 8
+    xs = _oracle.random_walk(n)
+    xs[11] = xs[10]                               # a zero wish distance: no constraint
+    x0 = _oracle.noisy_init(xs)
+    w = _oracle.wish_from_coords(xs)
+    if not f64:
+        w = w.astype(numpy.float32).astype(numpy.float64)
+    lr = 1.0 / (2 * n)
+    X1, h1 = oracle.solve(w, x0, k, lr, f64=f64)
+    Xg, hg = _oracle.solve_gen_mt(xs, x0, k, lr, 3, vw=vw, f64=f64)
+    assert numpy.abs(Xg - X1).max() < 1e-12 * numpy.abs(X1).max()
+    assert numpy.abs(hg / h1 - 1).max() < 1e-12
+    # momentum twin
+    X2, h2 = oracle.solve_momentum(w, x0, k, lr, 0.4, f64=f64)
+    Xm, hm = _oracle.solve_gen_mt(xs, x0, k, lr, 2, vw=vw, mu=0.4, f64=f64)
+    assert numpy.abs(Xm - X2).max() < 1e-12 * numpy.abs(X2).max()
+    assert numpy.abs(hm / h2 - 1).max() < 1e-12
+    # block-sparse: the diagonal tiles and one band
+    ti, tj = _oracle.dense_tiles(n, vw)
+    keep = (tj - ti) <= 1
+    tiles = (ti[keep], tj[keep])
+    mask = numpy.zeros((n, n), dtype=bool)
+    for a, b in zip(*tiles):
+        mask[a * vw:(a + 1) * vw, b * vw:(b + 1) * vw] = True
+    mask |= mask.T
+    ws = numpy.where(mask, w, 0.0)
+    X3, h3 = oracle.solve(ws, x0, k, lr, f64=f64)
+    Xs, hs = _oracle.solve_gen_mt(xs, x0, k, lr, 4, tiles=tiles, vw=vw, f64=f64)
+    assert numpy.abs(Xs - X3).max() < 1e-12 * numpy.abs(X3).max()
+    assert numpy.abs(hs / h3 - 1).max() < 1e-12
+
+
 def test_solver_oracle_equals_sklearn_smacof_on_a_complete_map(oracle):
     """S0 has no reference to pin to, so the oracle's solver is
     additionally pinned to a NAMED third-party algorithm: for a complete wish matrix, one

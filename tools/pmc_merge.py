@@ -1,5 +1,5 @@
 """Merge gpurun_out/pmc_entry_*.json (written by tools_pmc.sh on the GPU box) into
-profiles/pmc_latest.json: one entry per (bins, dtype, gpus); a newer entry replaces the
+profiles/pmc_latest.json: one entry per (bins, dtype, gpus, workload); a newer entry replaces the
 older one for the same key.  bench.py replays `hbm_bytes_per_launch` as roofline.traffic."""
 import glob, json, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ try:
 except (OSError, ValueError):
     d = {}
 entries = d.get("entries", [d] if d.get("bins") else [])
-key = lambda e: (e["bins"], e["dtype"], e.get("gpus", 1))
+key = lambda e: (e["bins"], e["dtype"], e.get("gpus", 1), e.get("workload", "dense"))
 table = {key(e): e for e in entries}
 for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_entry_%s*.json" % (sys.argv[1] if len(sys.argv) > 1 else "")))):
     e = json.load(open(f))
