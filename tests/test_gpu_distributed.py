@@ -129,11 +129,11 @@ def _worker_genome(rank, world, port, n, k, q):
 
 
 def _band_tiles(n, vw=512, width=2):
-    nb = -(-n // vw)
-    tj, ti = numpy.meshgrid(numpy.arange(nb), numpy.arange(nb))
-    sel = (ti <= tj) & (tj - ti <= width)
-    order = numpy.lexsort((ti[sel], tj[sel]))
-    return ti[sel][order].astype(numpy.int32), tj[sel][order].astype(numpy.int32)
+    """BASELINE config 5's own tile list -- what `bench.py --workload genome10kb` runs: one
+    block per hg19 chromosome + a 1000-bin band (blueberry_amd.solver.tiles_from_blocks)."""
+    from blueberry_amd.solver import tiles_from_blocks
+    from blueberry_amd.utils import genome_boundaries
+    return tiles_from_blocks(n, genome_boundaries(n), 1000, "float32")[0]
 
 
 def _worker_band(rank, world, port, n, k, lr, q):
@@ -163,16 +163,17 @@ def _worker_band(rank, world, port, n, k, lr, q):
 
 
 def test_config5_shape_four_ranks_over_the_peer_exchange():
-    """BASELINE config 5's shape at its real size (N = 309,568 bins, fp32, blocked-sparse:
-    the tiles within two tile-diagonals of the main one) on FOUR ranks -- four processes
-    sharing the test box's GPU, partial gradients of 929 k coordinates summed through the
-    peer exchange every iteration -- against the same iterations on one rank (1e-5), the
-    ranks bit-identical among themselves."""
+    """BASELINE config 5 at its real size and on the tile list bench.py times (N = 309,568
+    bins, fp32, blocked-sparse: one block per chromosome + a band, 10.5 GB of units split
+    four ways) on FOUR ranks -- four processes sharing the test box's GPU, partial gradients
+    of 929 k coordinates summed through the peer exchange every iteration -- against the
+    same iterations on one rank (1e-5), the ranks bit-identical among themselves."""
     import torch.multiprocessing as mp
     from blueberry_amd.solver import HipEngine
     from tests import _oracle
+    from blueberry_amd.solver import max_degree
     n, k, world = 309568, 4, 4
-    lr = 1.0 / (2 * 3 * 512)
+    lr = 1.0 / (2 * max_degree(n, _band_tiles(n), "float32"))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -469,3 +469,37 @@ def test_no_product_kernel_spills():
             assert v["vgpr"] <= 128, (k, v)
         else:                                 # fp64: two waves per SIMD
             assert v["vgpr"] <= 256, (k, v)
+
+
+def test_genome_boundaries_and_block_tile_list():
+    """BASELINE config 5's tile list (bench.py --workload genome10kb): hg19 at 10 kb is
+    309,568 bins, at 50 kb 61,914; tiles_from_blocks keeps exactly the tiles
+    that hold a same-chromosome pair or a pair within the band, in device order, and
+    counts the stored pairs i < j < n -- checked against a brute-force mask."""
+    from blueberry_amd.solver import max_degree, tiles_from_blocks
+    from blueberry_amd.utils import genome_boundaries
+    b = genome_boundaries()
+    assert b[0] == 0 and b[-1] == 309568 and len(b) == 25 and (numpy.diff(b) > 0).all()
+    assert b[1] == 24926                                  # chr1 at 10 kb (config 3's size)
+    assert genome_boundaries(resolution=50000)[-1] == 61914
+    n, band = 5000, 300
+    bs = genome_boundaries(n)
+    assert bs[-1] == n and len(bs) == 25
+    (ti, tj), pairs = tiles_from_blocks(n, bs, band, "float32")
+    vw = 512
+    chrom = numpy.searchsorted(bs, numpy.arange(n), side="right") - 1
+    i, j = numpy.triu_indices(n, 1)
+    wanted = (chrom[i] == chrom[j]) | (j - i <= band)
+    nb = -(-n // vw)
+    want_tiles = numpy.unique((j[wanted] // vw) * nb + i[wanted] // vw)
+    got = tj.astype(numpy.int64) * nb + ti
+    assert numpy.array_equal(got, want_tiles)             # same set, and (J, I) ascending
+    have = numpy.zeros((nb, nb), dtype=bool)
+    have[ti, tj] = True
+    assert pairs == int(have[i // vw, j // vw].sum())
+    deg = max_degree(n, (ti, tj), "float32")
+    cnt = numpy.bincount(i[have[i // vw, j // vw]], minlength=n) + \
+        numpy.bincount(j[have[i // vw, j // vw]], minlength=n)
+    assert cnt.max() <= deg <= n
+    with pytest.raises(ValueError):
+        tiles_from_blocks(n, [0, 10, 5, n], band, "float32")
