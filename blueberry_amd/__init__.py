@@ -22,7 +22,7 @@ from .utils import (HIGH_FITHIC_CUTOFF, LOW_FITHIC_CUTOFF, Q_LOWER_BOUND,  # noq
                     Q_UPPER_BOUND)
 from .band import count_band_regions  # noqa: F401
 from .datatypes import ContactMap, EigenNoConvergence, FithicContactMap  # noqa: F401
-from .solver import HipEngine, StructureSolver  # noqa: F401
+from .solver import HipEngine, RankDeficient, StructureSolver  # noqa: F401
 from .stats import benjamini_hochberg, downsample  # noqa: F401
 
 __version__ = "0.1.0"

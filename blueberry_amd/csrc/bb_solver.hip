@@ -70,6 +70,10 @@ struct bb_solver {
     unsigned defer_attr_done = 0;  // kernel variants whose dynamic-LDS ceiling was raised
     int64_t hist_cap = 0, hist_n = 0;
     bool have_wish = false, have_coords = false, grad_pending = false;
+    // exchange_sum(): while set, the reduce / exchange kernels leave the plain sum over the
+    // ranks HERE instead of stepping the coordinates (X := this buffer, zeroed; V := d_V;
+    // mu = 0, lr = -1: 0 + (0 * v - (-1) * sum) is the sum, exactly)
+    void *sum_target = nullptr;
 
     bb::Rccl::Comm comm = nullptr;  // direct RCCL path (bb_solver_comm_init), else null
     bool comm_cached = false;       // the communicator belongs to the process-wide cache
@@ -485,9 +489,9 @@ void fill_reduce_params(bb_solver *s, ReduceParams<T> &p, int mode, double lr, d
 
 // The peer exchange in one launch (reduce_exchange_kernel): the caller has bumped peer_seq.
 template <typename T, bool W>
-int launch_exchange_t(bb_solver *s, double lr, double *stress_out) {
+int launch_exchange_t(bb_solver *s, double lr, double *stress_out, double scale) {
     ReduceParams<T> p;
-    fill_reduce_params<T>(s, p, kReducePeer, lr, stress_out, 2.0);
+    fill_reduce_params<T>(s, p, kReducePeer, lr, stress_out, scale);
     const int64_t es = sizeof(T);
     const unsigned segs = 3 * Lay<T, W>::VW / kRedWG;
     const dim3 grid((unsigned)s->L.n_blocks, segs);
@@ -511,16 +515,16 @@ void fill_reduce_params(bb_solver *s, ReduceParams<T> &p, int mode, double lr, d
                         double scale) {
     p.part = (const T *)s->d_part;
     p.stresspart = s->d_stresspart;
-    p.X = (T *)s->d_X;
+    p.X = s->sum_target ? (T *)s->sum_target : (T *)s->d_X;
     p.V = (T *)s->d_V;
-    p.mu = (T)s->momentum;
+    p.mu = s->sum_target ? T(0) : (T)s->momentum;
     p.scale = (T)scale;
     p.exch = (T *)s->d_exch;
     p.part_out = (T *)s->d_part + s->part2_off;
     p.stress_out = stress_out;
     p.n_pad = s->L.n_pad;
     p.n_waves = s->n_waves;
-    p.lr = (T)lr;
+    p.lr = s->sum_target ? T(-1) : (T)lr;
     p.peer = nullptr;
     p.peer_counter = s->d_peer_counter;
     p.peer_state = s->d_peer_state;
@@ -575,8 +579,8 @@ int launch_grad(bb_solver *s, int op = kOpStress, const void *x_in = nullptr) {
 int launch_reduce(bb_solver *s, int mode, double lr, double *stress_out, double scale = 2.0) {
     return BB_BY_LAYOUT(s, launch_reduce_t, s, mode, lr, stress_out, scale);
 }
-int launch_exchange(bb_solver *s, double lr, double *stress_out) {
-    return BB_BY_LAYOUT(s, launch_exchange_t, s, lr, stress_out);
+int launch_exchange(bb_solver *s, double lr, double *stress_out, double scale = 2.0) {
+    return BB_BY_LAYOUT(s, launch_exchange_t, s, lr, stress_out, scale);
 }
 
 hipEvent_t *timing_slot(bb_solver *s) {
@@ -1331,6 +1335,68 @@ int bb_solver_iterate_dist(bb_solver *s, int64_t iters, double lr) {
     return BB_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// The receiving half of the two-launch peer exchange (peer_receive_kernel): wait for every
+// rank's flag of exchange `peer_seq`, X <- X + (mu V - lr * sum over the ranks in rank order).
+int launch_peer_receive(bb_solver *s, void *X, double lr, double mu, double *stress_out) {
+    const int64_t n3 = s->L.n_pad * 3, es = bb::elem_size(s->dtype);
+    const unsigned grid = (unsigned)std::min<int64_t>((n3 + 255) / 256, kPeerReceiveWGs);
+    const char *arena = (const char *)s->peer_arena +
+                        (int64_t)(s->peer_seq & 1) * s->world * s->peer_slot_elems * es;
+    const unsigned long long *flags =
+        (const unsigned long long *)((const char *)s->peer_arena + peer_flags_offset(s));
+    // the flag pointers are the second half of a PeerTable (same for both parities)
+    unsigned long long *const *poison =
+        (unsigned long long *const *)((const char *)s->d_peer_table + kMaxPeers * sizeof(void *));
+    if (s->dtype == BB_F32)
+        BB_HIP_CHECK(bb::launch(peer_receive_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
+                                (float *)X, (float *)s->d_V, (const float *)arena, flags, poison,
+                                s->world, s->peer_slot_elems, n3, (float)lr, (float)mu, stress_out,
+                                s->peer_seq, s->d_peer_state, s->peer_limit_ticks));
+    else
+        BB_HIP_CHECK(bb::launch(peer_receive_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
+                                (double *)X, (double *)s->d_V, (const double *)arena, flags, poison,
+                                s->world, s->peer_slot_elems, n3, lr, mu, stress_out, s->peer_seq,
+                                s->d_peer_state, s->peer_limit_ticks));
+    return BB_OK;
+}
+
+// The plain SUM over the ranks of what the last sweep left in the partials (scale 1: a
+// matvec, not a gradient), into the exchange buffer [0, 3 n_pad) of every rank, enqueued on
+// the solver's stream: the reduce alone on one rank; the peer exchange (either form; the
+// ranks' partials are added in rank order, so every rank holds the same bits) when the
+// arenas are connected; else the library's RCCL communicator.  The step-taking kernels are
+// used as they are -- see bb_solver::sum_target.  d_V is left holding the sum as well.
+int exchange_sum(bb_solver *s) {
+    const int64_t n3 = s->L.n_pad * 3, es = bb::elem_size(s->dtype);
+    if (s->peer_connected) {        // (also a one-rank solver that pushes to itself: a rehearsal)
+        BB_HIP_CHECK(hipMemsetAsync(s->d_exch, 0, (size_t)(n3 * es), s->stream));
+        s->peer_seq++;
+        s->sum_target = s->d_exch;
+        int rc;
+        if (s->peer_fused && s->red_slices > 0) {
+            rc = launch_exchange(s, -1.0, s->d_stress_scalar, 1.0);
+        } else {
+            rc = launch_reduce(s, kReducePeer, 0.0, nullptr, 1.0);
+            if (rc == BB_OK) rc = launch_peer_receive(s, s->d_exch, -1.0, 0.0, s->d_stress_scalar);
+        }
+        s->sum_target = nullptr;
+        return rc;
+    }
+    if (s->comm) {
+        BB_TRY(launch_reduce(s, kReduceExchange, 0.0, nullptr, 1.0));
+        return enqueue_allreduce(s);
+    }
+    if (s->world == 1) return launch_reduce(s, kReduceExchange, 0.0, nullptr, 1.0);
+    return bb::fail(BB_ERR_STATE, "no exchange between the ranks is set up (bb_solver_peer_connect "
+                                  "or bb_solver_comm_init / _attach first)");
+}
+}  // namespace
+
+extern "C" {
+
 int bb_solver_peer_export(bb_solver *s, void *handle_out) {
     BB_REQUIRE(s != nullptr && handle_out != nullptr, "bb_solver_peer_export: NULL argument");
     BB_REQUIRE(s->world <= kMaxPeers, "bb_solver_peer_export: world > 16");
@@ -1526,8 +1592,6 @@ int bb_solver_iterate_peer(bb_solver *s, int64_t iters, double lr) {
     if (s->hist_n + iters > s->hist_cap)
         return bb::fail(BB_ERR_STATE, "bb_solver_iterate_peer: stress history full");
     BB_TRY(bb::enter_device(s->device));
-    const int64_t n3 = s->L.n_pad * 3, es = bb::elem_size(s->dtype);
-    const unsigned grid = (unsigned)std::min<int64_t>((n3 + 255) / 256, kPeerReceiveWGs);
     for (int64_t k = 0; k < iters; ++k) {
         hipEvent_t *ev = timing_slot(s);
         if (ev) BB_HIP_CHECK(hipEventRecord(ev[0], s->stream));
@@ -1543,25 +1607,7 @@ int bb_solver_iterate_peer(bb_solver *s, int64_t iters, double lr) {
         }
         BB_TRY(launch_reduce(s, kReducePeer, 0.0, nullptr));
         if (ev) BB_HIP_CHECK(hipEventRecord(ev[2], s->stream));
-        const char *arena = (const char *)s->peer_arena +
-                            (int64_t)(s->peer_seq & 1) * s->world * s->peer_slot_elems * es;
-        const unsigned long long *flags =
-            (const unsigned long long *)((const char *)s->peer_arena + peer_flags_offset(s));
-        // the flag pointers are the second half of a PeerTable (same for both parities)
-        unsigned long long *const *poison =
-            (unsigned long long *const *)((const char *)s->d_peer_table + kMaxPeers * sizeof(void *));
-        if (s->dtype == BB_F32)
-            BB_HIP_CHECK(bb::launch(peer_receive_kernel<float>, dim3(grid), dim3(256), 0, s->stream,
-                                    (float *)s->d_X, (float *)s->d_V, (const float *)arena, flags,
-                                    poison, s->world, s->peer_slot_elems, n3, (float)lr,
-                                    (float)s->momentum, s->d_stress_hist + s->hist_n, s->peer_seq,
-                                    s->d_peer_state, s->peer_limit_ticks));
-        else
-            BB_HIP_CHECK(bb::launch(peer_receive_kernel<double>, dim3(grid), dim3(256), 0, s->stream,
-                                    (double *)s->d_X, (double *)s->d_V, (const double *)arena, flags,
-                                    poison, s->world, s->peer_slot_elems, n3, lr, s->momentum,
-                                    s->d_stress_hist + s->hist_n, s->peer_seq, s->d_peer_state,
-                                    s->peer_limit_ticks));
+        BB_TRY(launch_peer_receive(s, s->d_X, lr, s->momentum, s->d_stress_hist + s->hist_n));
         s->hist_n++;
     }
     return BB_OK;
@@ -1925,32 +1971,6 @@ int bb_solver_traffic(const bb_solver *s, int64_t *unit_bytes, int64_t *pairs_de
 namespace {
 
 // small dense helpers on the host (3 x 3, row-major)
-bool chol3_inv_upper(const double *g, double *rinv) {
-    // g = R^T R (R upper); returns R^-1 (upper).  False if g is not positive definite.
-    double r[9] = {0};
-    for (int j = 0; j < 3; ++j) {
-        double d = g[j * 3 + j];
-        for (int k = 0; k < j; ++k) d -= r[k * 3 + j] * r[k * 3 + j];
-        if (!(d > 0.0)) return false;
-        r[j * 3 + j] = sqrt(d);
-        for (int c = j + 1; c < 3; ++c) {
-            double v = g[j * 3 + c];
-            for (int k = 0; k < j; ++k) v -= r[k * 3 + j] * r[k * 3 + c];
-            r[j * 3 + c] = v / r[j * 3 + j];
-        }
-    }
-    for (int q = 0; q < 9; ++q) rinv[q] = 0.0;
-    for (int j = 0; j < 3; ++j) {
-        rinv[j * 3 + j] = 1.0 / r[j * 3 + j];
-        for (int i = j - 1; i >= 0; --i) {
-            double v = 0.0;
-            for (int k = i + 1; k <= j; ++k) v -= r[i * 3 + k] * rinv[k * 3 + j];
-            rinv[i * 3 + j] = v / r[i * 3 + i];
-        }
-    }
-    return true;
-}
-
 void jacobi3(double *a, double *z) {   // a symmetric 3 x 3 -> eigenvalues on its diagonal, vectors in z
     for (int q = 0; q < 9; ++q) z[q] = (q % 4 == 0) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 50; ++sweep) {
@@ -1986,14 +2006,20 @@ template <typename T>
 int spectral_init_t(bb_solver *s, int n_iter, const double *v0) {
     const int64_t n = s->L.n_bins, n_pad = s->L.n_pad, n3 = n_pad * 3;
     if (!s->d_mv_in) BB_TRY(dev_alloc((char **)&s->d_mv_in, n3 * (int64_t)sizeof(T)));
-    double *dV = nullptr, *dZ = nullptr, *dS = nullptr;     // V, Z: (n_pad,3) doubles; dS: 12 sums
-    bb::DevBuf bV, bZ, bS;
+    // V, Z: (n_pad,3) doubles; dS: 12 sums (the two host steps at the end); dP: per-workgroup
+    // partial sums of a pass; dA: the 3 x 3 maps the passes hand to one another; dF: rank-loss flag
+    bb::DevBuf bV, bZ, bS, bP, bA, bF;
     if (bV.alloc((size_t)n3 * 8) != hipSuccess || bZ.alloc((size_t)n3 * 8) != hipSuccess ||
-        bS.alloc(12 * 8) != hipSuccess)
+        bS.alloc(12 * 8) != hipSuccess || bP.alloc((size_t)kSpMaxGroups * 12 * 8) != hipSuccess ||
+        bA.alloc(4 * sizeof(Affine3)) != hipSuccess || bF.alloc(sizeof(int)) != hipSuccess)
         return bb::fail(BB_ERR_NOMEM, "bb_solver_spectral_init: out of device memory");
-    dV = (double *)bV.p; dZ = (double *)bZ.p; dS = (double *)bS.p;
+    double *dV = (double *)bV.p, *dZ = (double *)bZ.p, *dS = (double *)bS.p, *dP = (double *)bP.p;
+    Affine3 *dA = (Affine3 *)bA.p;
+    int *dF = (int *)bF.p;
     hipStream_t st = s->stream;
-    const dim3 gvec((unsigned)((n_pad + 255) / 256)), b256(256);
+    const dim3 gvec((unsigned)((n_pad + kSpWG - 1) / kSpWG)), bwg(kSpWG);
+    const int groups = (int)std::min<int64_t>(kSpMaxGroups, (n_pad + kSpWG - 1) / kSpWG);
+    const dim3 ggrp((unsigned)groups);
     const Affine3 ident = {{0, 0, 0}, {1, 0, 0, 0, 1, 0, 0, 0, 1}, 1.0};
     double sums[12];
     auto fetch_sums = [&]() -> int {
@@ -2001,59 +2027,55 @@ int spectral_init_t(bb_solver *s, int n_iter, const double *v0) {
         BB_HIP_CHECK(hipMemcpy(sums, dS, sizeof(sums), hipMemcpyDeviceToHost));
         return BB_OK;
     };
-    // Z <- orthonormal basis of span(Z) by Cholesky-QR, twice (the second pass removes what
-    // the first leaves at cond(Z)^2 * eps); result in dV
-    auto orthonormalise = [&](double *src, double *dst) -> int {
-        double *a = src, *b = dst;
-        for (int pass = 0; pass < 2; ++pass) {
-            BB_HIP_CHECK(bb::launch(gram3_kernel<double, double>, dim3(1), dim3(1024), 0, st,
-                                    (const double *)a, (const double *)a, n, dS));
-            BB_TRY(fetch_sums());
-            Affine3 q = ident;
-            if (!chol3_inv_upper(sums, q.m))
-                return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: the iterate lost rank "
-                                              "(fewer than 3 independent directions in the map)");
-            BB_HIP_CHECK(bb::launch(affine3_kernel<double, double>, gvec, b256, 0, st,
-                                    (const double *)a, b, n, n_pad, q));
-            std::swap(a, b);
-        }
-        // two passes: the result is back in `src`; callers pass (dZ, dV) and read dZ... keep simple:
-        if (a != dst)
-            BB_HIP_CHECK(hipMemcpyAsync(dst, a, (size_t)n3 * 8, hipMemcpyDeviceToDevice, st));
+    auto finalize = [&](int mode, double scale, Affine3 *out) -> int {
+        BB_HIP_CHECK(bb::launch(sp_finalize_kernel, dim3(1), dim3(768), 0, st, (const double *)dP,
+                                groups, n, mode, scale, out, dF));
         return BB_OK;
     };
-    // Z = -1/2 J (D o D) J V  (J = I - 11'/n): centre, sweep, centre
-    auto apply_B = [&](const double *V, double *Z) -> int {
-        BB_HIP_CHECK(bb::launch(gram3_kernel<double, double>, dim3(1), dim3(1024), 0, st, V, V, n, dS));
-        BB_TRY(fetch_sums());
-        Affine3 c = ident;
-        for (int k = 0; k < 3; ++k) c.mean[k] = sums[9 + k] / (double)n;
-        BB_HIP_CHECK(bb::launch(affine3_kernel<double, T>, gvec, b256, 0, st, V, (T *)s->d_mv_in, n,
-                                n_pad, c));
+    // dZ (any basis of the subspace, its 12 sums in dP) -> dV orthonormal by Cholesky-QR, twice
+    // (the second pass removes what the first leaves at cond(Z)^2 * eps), and the sweep's
+    // right-hand sides d_mv_in = (T)(V - mean V): three kernels + two 3 x 3 steps, no host
+    auto orthonormalise = [&]() -> int {
+        BB_TRY(finalize(kSpChol, 1.0, dA + 1));
+        BB_HIP_CHECK(bb::launch(sp_affine_stats_kernel<double>, ggrp, bwg, 0, st, (const double *)dZ, dV,
+                                n, n_pad, (const Affine3 *)(dA + 1), dP));
+        BB_TRY(finalize(kSpCholMean, 1.0, dA + 2));
+        BB_HIP_CHECK(bb::launch(sp_affine_centre_kernel<T>, gvec, bwg, 0, st, (const double *)dV, dV,
+                                (T *)s->d_mv_in, n, n_pad, (const Affine3 *)(dA + 2)));
+        return BB_OK;
+    };
+    // dZ = -1/2 J (D o D) J V  (J = I - 11'/n) from the centred V in d_mv_in: sweep, sum over
+    // the ranks, centre; the 12 sums of dZ are left in dP
+    auto apply_B = [&]() -> int {
         BB_TRY(launch_grad(s, kOpMatvec2, s->d_mv_in));
-        BB_TRY(launch_reduce(s, kReduceExchange, 0.0, nullptr, 1.0));
-        BB_HIP_CHECK(bb::launch(gram3_kernel<T, T>, dim3(1), dim3(1024), 0, st, (const T *)s->d_exch,
-                                (const T *)s->d_exch, n, dS));
-        BB_TRY(fetch_sums());
-        Affine3 w = ident;
-        for (int k = 0; k < 3; ++k) w.mean[k] = sums[9 + k] / (double)n;
-        w.scale = -0.5;
-        BB_HIP_CHECK(bb::launch(affine3_kernel<T, double>, gvec, b256, 0, st, (const T *)s->d_exch, Z,
-                                n, n_pad, w));
+        BB_TRY(exchange_sum(s));
+        BB_HIP_CHECK(bb::launch(sp_stats_kernel<T>, ggrp, bwg, 0, st, (const T *)s->d_exch, n, n_pad, dP));
+        BB_TRY(finalize(kSpMean, -0.5, dA));
+        BB_HIP_CHECK(bb::launch(sp_affine_stats_kernel<T>, ggrp, bwg, 0, st, (const T *)s->d_exch, dZ, n,
+                                n_pad, (const Affine3 *)dA, dP));
         return BB_OK;
     };
+    BB_HIP_CHECK(hipMemsetAsync(dF, 0, sizeof(int), st));
+    BB_HIP_CHECK(hipMemsetAsync(s->d_V, 0, (size_t)n3 * sizeof(T), st));   // exchange_sum reads it
     BB_HIP_CHECK(hipMemsetAsync(dZ, 0, (size_t)n3 * 8, st));
     BB_HIP_CHECK(hipMemcpyAsync(dZ, v0, (size_t)n * 24, hipMemcpyHostToDevice, st));
-    BB_TRY(orthonormalise(dZ, dV));
+    BB_HIP_CHECK(bb::launch(sp_stats_kernel<double>, ggrp, bwg, 0, st, (const double *)dZ, n, n_pad, dP));
+    BB_TRY(orthonormalise());
     for (int it = 0; it < n_iter; ++it) {
-        BB_TRY(apply_B(dV, dZ));
-        BB_TRY(orthonormalise(dZ, dV));
+        BB_TRY(apply_B());
+        BB_TRY(orthonormalise());
     }
-    // Rayleigh-Ritz on span(V): M = sym(V^T B V), X0 = V E sqrt(max(lambda, 0))
-    BB_TRY(apply_B(dV, dZ));
+    // Rayleigh-Ritz on span(V): M = sym(V^T B V), X0 = V E sqrt(max(lambda, 0)).  From here on
+    // the host takes part: three reads of 12 doubles for the whole start.
+    BB_TRY(apply_B());
     BB_HIP_CHECK(bb::launch(gram3_kernel<double, double>, dim3(1), dim3(1024), 0, st, (const double *)dV,
                             (const double *)dZ, n, dS));
     BB_TRY(fetch_sums());
+    int lost = 0;
+    BB_HIP_CHECK(hipMemcpy(&lost, dF, sizeof(int), hipMemcpyDeviceToHost));
+    if (lost)
+        return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: the iterate lost rank "
+                                      "(fewer than 3 independent directions in the map)");
     double m[9], z[9];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) m[i * 3 + j] = 0.5 * (sums[i * 3 + j] + sums[j * 3 + i]);
@@ -2076,8 +2098,8 @@ int spectral_init_t(bb_solver *s, int n_iter, const double *v0) {
         const double sg = side < 0.0 ? -1.0 : 1.0;
         for (int r = 0; r < 3; ++r) f.m[r * 3 + c] = sg * z[r * 3 + order[c]] * sqrt(lam);
     }
-    BB_HIP_CHECK(bb::launch(affine3_kernel<double, T>, gvec, b256, 0, st, (const double *)dV,
-                            (T *)s->d_X, n, n_pad, f));
+    BB_HIP_CHECK(bb::launch(affine3_kernel<double, T>, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0,
+                            st, (const double *)dV, (T *)s->d_X, n, n_pad, f));
     BB_HIP_CHECK(hipMemsetAsync(s->d_V, 0, (size_t)n3 * sizeof(T), st));
     BB_HIP_CHECK(hipStreamSynchronize(st));
     return BB_OK;
@@ -2089,9 +2111,11 @@ extern "C" int bb_solver_spectral_init(bb_solver *s, int n_iter, const double *v
     BB_REQUIRE(s != nullptr && v0 != nullptr, "bb_solver_spectral_init: NULL argument");
     BB_REQUIRE(n_iter >= 0 && n_iter <= 100000, "bb_solver_spectral_init: bad n_iter");
     if (!s->have_wish) return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: no wish distances set");
-    if (s->world != 1)
-        return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: one rank only (with world > 1 the "
-                                      "caller sums bb_solver_matvec_sq over the ranks)");
+    if (s->world != 1 && !s->peer_connected && !s->comm)
+        return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: with world > 1 the ranks need their "
+                                      "exchange first (bb_solver_peer_connect, or bb_solver_comm_init "
+                                      "/ _attach); without one the caller sums bb_solver_matvec_sq "
+                                      "over the ranks");
     if (s->grad_pending)
         return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: a bb_solver_grad is pending");
     BB_REQUIRE(s->L.n_bins >= 3, "bb_solver_spectral_init: needs at least 3 bins");

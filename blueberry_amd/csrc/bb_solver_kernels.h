@@ -2186,6 +2186,193 @@ __global__ __launch_bounds__(256) void affine3_kernel(const TI *__restrict__ in,
     out[3 * i] = (TO)o0; out[3 * i + 1] = (TO)o1; out[3 * i + 2] = (TO)o2;
 }
 
+// ---- the same N x 3 algebra WITHOUT a host round trip (round 4) -------------------------
+// bb_solver_spectral_init used to read 12 sums back four times per product (centre, centre,
+// two Cholesky-QR passes): four stream synchronisations around a sweep that takes 0.1 ms on a
+// 1/8 share.  Now the 3 x 3 work stays on the device: every pass over an (n,3) array is ONE
+// kernel that applies the affine map the previous step left in device memory and leaves the
+// 12 sums of its OUTPUT (Gram matrix + column sums) as per-workgroup partials; a one-workgroup
+// kernel adds them in a fixed order, does the 3 x 3 step (mean, or Cholesky factor and its
+// inverse) and writes the next map.  A factor that is not positive definite (the iterate lost
+// rank) raises a flag the host reads once, at the end.  Sums are in double, fixed order:
+// bitwise reproducible, and identical on every rank of a multi-rank start.
+constexpr int kSpWG = 256;          // threads per workgroup of the passes
+constexpr int kSpMaxGroups = 256;   // partials per pass
+
+// rows [r0, r1) of workgroup g of G over n_pad rows
+__device__ __forceinline__ void sp_rows(int64_t n_pad, int64_t &r0, int64_t &r1) {
+    const int64_t per = (n_pad + gridDim.x - 1) / gridDim.x;
+    r0 = (int64_t)blockIdx.x * per;
+    r1 = r0 + per < n_pad ? r0 + per : n_pad;
+}
+// the workgroup's 12 sums -> partial[blockIdx.x * 12 ..]: lanes by shuffle, waves through LDS
+__device__ __forceinline__ void sp_store_partial(double (&acc)[12], double *__restrict__ partial) {
+    __shared__ double sh[12][kSpWG / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        double v = acc[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) sh[q][wv] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < kSpWG / 64; ++k) v += sh[threadIdx.x][k];
+        partial[(int64_t)blockIdx.x * 12 + threadIdx.x] = v;
+    }
+}
+__device__ __forceinline__ void sp_accumulate(double (&acc)[12], double a0, double a1, double a2) {
+    acc[0] = fma(a0, a0, acc[0]); acc[1] = fma(a0, a1, acc[1]); acc[2] = fma(a0, a2, acc[2]);
+    acc[3] = fma(a1, a0, acc[3]); acc[4] = fma(a1, a1, acc[4]); acc[5] = fma(a1, a2, acc[5]);
+    acc[6] = fma(a2, a0, acc[6]); acc[7] = fma(a2, a1, acc[7]); acc[8] = fma(a2, a2, acc[8]);
+    acc[9] += a0; acc[10] += a1; acc[11] += a2;
+}
+
+// partial sums of in^T in and of in's columns (rows < n_bins)
+template <typename TI>
+__global__ __launch_bounds__(kSpWG) void sp_stats_kernel(const TI *__restrict__ in, int64_t n_bins,
+                                                         int64_t n_pad, double *__restrict__ partial) {
+    int64_t r0, r1;
+    sp_rows(n_pad, r0, r1);
+    double acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0;
+    for (int64_t i = r0 + threadIdx.x; i < r1 && i < n_bins; i += kSpWG)
+        sp_accumulate(acc, (double)in[3 * i], (double)in[3 * i + 1], (double)in[3 * i + 2]);
+    sp_store_partial(acc, partial);
+}
+
+// out_i = a->scale * ((in_i - a->mean) a->m) for rows < n_bins (0 beyond), the map read from
+// device memory, + the partial sums of the OUTPUT.  In place (in == out) is fine: a thread
+// reads its row before it writes it.
+template <typename TI>
+__global__ __launch_bounds__(kSpWG) void sp_affine_stats_kernel(const TI *in, double *out,
+                                                                int64_t n_bins, int64_t n_pad,
+                                                                const Affine3 *__restrict__ a,
+                                                                double *__restrict__ partial) {
+    int64_t r0, r1;
+    sp_rows(n_pad, r0, r1);
+    const Affine3 A = *a;
+    double acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0;
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += kSpWG) {
+        double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+        if (i < n_bins) {
+            const double x0 = (double)in[3 * i] - A.mean[0], x1 = (double)in[3 * i + 1] - A.mean[1],
+                         x2 = (double)in[3 * i + 2] - A.mean[2];
+            o0 = A.scale * (x0 * A.m[0] + x1 * A.m[3] + x2 * A.m[6]);
+            o1 = A.scale * (x0 * A.m[1] + x1 * A.m[4] + x2 * A.m[7]);
+            o2 = A.scale * (x0 * A.m[2] + x1 * A.m[5] + x2 * A.m[8]);
+            sp_accumulate(acc, o0, o1, o2);
+        }
+        out[3 * i] = o0; out[3 * i + 1] = o1; out[3 * i + 2] = o2;
+    }
+    sp_store_partial(acc, partial);
+}
+
+// The last pass of an orthonormalisation: V = V' a[0].m, written as double, and the sweep's
+// right-hand sides mv = (T)(V - a[1].mean) -- V centred, in the solver's type -- in one go.
+template <typename T>
+__global__ __launch_bounds__(kSpWG) void sp_affine_centre_kernel(const double *in, double *out_v,
+                                                                 T *__restrict__ out_mv,
+                                                                 int64_t n_bins, int64_t n_pad,
+                                                                 const Affine3 *__restrict__ a) {
+    const int64_t i = (int64_t)blockIdx.x * kSpWG + threadIdx.x;
+    if (i >= n_pad) return;
+    double o0 = 0.0, o1 = 0.0, o2 = 0.0, c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    if (i < n_bins) {
+        const Affine3 A = a[0];
+        const double x0 = in[3 * i], x1 = in[3 * i + 1], x2 = in[3 * i + 2];
+        o0 = x0 * A.m[0] + x1 * A.m[3] + x2 * A.m[6];
+        o1 = x0 * A.m[1] + x1 * A.m[4] + x2 * A.m[7];
+        o2 = x0 * A.m[2] + x1 * A.m[5] + x2 * A.m[8];
+        c0 = o0 - a[1].mean[0]; c1 = o1 - a[1].mean[1]; c2 = o2 - a[1].mean[2];
+    }
+    out_v[3 * i] = o0; out_v[3 * i + 1] = o1; out_v[3 * i + 2] = o2;
+    out_mv[3 * i] = (T)c0; out_mv[3 * i + 1] = (T)c1; out_mv[3 * i + 2] = (T)c2;
+}
+
+// g = R^T R (R upper) -> R^-1 (upper), 3 x 3 row-major.  False if g is not positive definite.
+__host__ __device__ inline bool sp_chol3_inv_upper(const double *g, double *rinv) {
+    double r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < 3; ++j) {
+        double d = g[j * 3 + j];
+        for (int k = 0; k < j; ++k) d -= r[k * 3 + j] * r[k * 3 + j];
+        if (!(d > 0.0)) return false;
+        r[j * 3 + j] = sqrt(d);
+        for (int c = j + 1; c < 3; ++c) {
+            double v = g[j * 3 + c];
+            for (int k = 0; k < j; ++k) v -= r[k * 3 + j] * r[k * 3 + c];
+            r[j * 3 + c] = v / r[j * 3 + j];
+        }
+    }
+    for (int q = 0; q < 9; ++q) rinv[q] = 0.0;
+    for (int j = 0; j < 3; ++j) {
+        rinv[j * 3 + j] = 1.0 / r[j * 3 + j];
+        for (int i = j - 1; i >= 0; --i) {
+            double v = 0.0;
+            for (int k = i + 1; k <= j; ++k) v -= r[i * 3 + k] * rinv[k * 3 + j];
+            rinv[i * 3 + j] = v / r[i * 3 + i];
+        }
+    }
+    return true;
+}
+
+// One workgroup of 12 waves: wave q adds value q of the `groups` partials (lane l takes the
+// groups l, l + 64, ... in order, then a fixed shuffle tree), thread 0 does the 3 x 3 step.
+//   kSpMean     out[0] = { mean = column sums / n, M = I, scale }           (centring)
+//   kSpChol     out[0] = { 0, R^-1, 1 } with R^T R = the Gram matrix        (Cholesky-QR pass)
+//   kSpCholMean the same, and out[1].mean = (column sums / n) R^-1: the mean of what the
+//               map is about to produce (sp_affine_centre_kernel)
+// A Gram matrix that is not positive definite sets *flag and leaves the identity.
+enum { kSpMean = 0, kSpChol = 1, kSpCholMean = 2 };
+__global__ __launch_bounds__(768) void sp_finalize_kernel(const double *__restrict__ partial,
+                                                          int groups, int64_t n_bins, int mode,
+                                                          double scale, Affine3 *__restrict__ out,
+                                                          int *__restrict__ flag) {
+    __shared__ double tot[12];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    double v = 0.0;
+    for (int g = lane; g < groups; g += 64) v += partial[(int64_t)g * 12 + q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) tot[q] = v;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    Affine3 A;
+    for (int k = 0; k < 3; ++k) A.mean[k] = 0.0;
+    for (int k = 0; k < 9; ++k) A.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    A.scale = 1.0;
+    if (mode == kSpMean) {
+        for (int k = 0; k < 3; ++k) A.mean[k] = tot[9 + k] / (double)n_bins;
+        A.scale = scale;
+        out[0] = A;
+        return;
+    }
+    double rinv[9];
+    if (!sp_chol3_inv_upper(tot, rinv)) {
+        *flag = 1;
+        out[0] = A;
+        if (mode == kSpCholMean) out[1] = A;
+        return;
+    }
+    for (int k = 0; k < 9; ++k) A.m[k] = rinv[k];
+    out[0] = A;
+    if (mode == kSpCholMean) {
+        Affine3 B = A;
+        const double m0 = tot[9] / (double)n_bins, m1 = tot[10] / (double)n_bins,
+                     m2 = tot[11] / (double)n_bins;
+        B.mean[0] = m0 * rinv[0] + m1 * rinv[3] + m2 * rinv[6];
+        B.mean[1] = m0 * rinv[1] + m1 * rinv[4] + m2 * rinv[7];
+        B.mean[2] = m0 * rinv[2] + m1 * rinv[5] + m2 * rinv[8];
+        out[1] = B;
+    }
+}
+
 template <typename T>
 __global__ void f64_to_T_kernel(const double *__restrict__ in, T *__restrict__ out, int64_t n) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;

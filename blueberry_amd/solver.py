@@ -21,6 +21,12 @@ _DTYPES = {"float32": _lib.BB_F32, "float64": _lib.BB_F64}
 _KINDS = {"wish": _lib.BB_KIND_WISH, "counts": _lib.BB_KIND_COUNTS}
 
 
+class RankDeficient(RuntimeError):
+    """The block power iteration of the device-resident spectral start lost rank: the map has
+    fewer than three independent directions (an empty or unconstrained map, fewer than 4 bins).
+    `fit()` then takes the host-driven start; every other library error propagates."""
+
+
 class HipEngine(object):
     """One rank's device state: thin, 1:1 over the bb_solver_* C-ABI."""
 
@@ -139,11 +145,16 @@ class HipEngine(object):
         return y
 
     def spectral_init_device(self, n_iter, v0):
-        """Classical-MDS start computed and left on the device (one rank):
-        `bb_solver_spectral_init`.  v0: (n_bins, 3) start of the block power iteration."""
+        """Classical-MDS start computed and left on the device: `bb_solver_spectral_init`.
+        v0: (n_bins, 3) start of the block power iteration (the same on every rank).  With
+        several ranks it is collective and needs their exchange set up first (peer arenas or
+        the library's communicator): the per-rank products are summed on the device, nothing
+        of size N crosses PCIe.  Raises RankDeficient when the iterate lost rank."""
         v0 = _check_coords(v0, self.n_bins)
-        _lib.check(self._lib.bb_solver_spectral_init(self._h, int(n_iter), _lib.as_f64_ptr(v0)),
-                   "bb_solver_spectral_init")
+        rc = self._lib.bb_solver_spectral_init(self._h, int(n_iter), _lib.as_f64_ptr(v0))
+        if rc == _lib.BB_ERR_STATE and "lost rank" in _lib.last_error():
+            raise RankDeficient(_lib.last_error())
+        _lib.check(rc, "bb_solver_spectral_init")
 
     def stress(self):
         out = _lib.c_dbl()
@@ -631,20 +642,32 @@ class StructureSolver(object):
             else:
                 eng.set_wish_dense(matrix, self.kind, self.alpha)
             on_device = False
-            if init is None and world == 1 and n >= 4 and hasattr(eng, "spectral_init_device"):
-                # 'spectral' on one rank: the whole block power iteration stays on the device.
-                # Its Cholesky-QR needs an iterate of full column rank; maps it cannot take --
-                # fewer than 4 bins (centring leaves at most 2 directions), an empty or
-                # unconstrained map -- go through the host form below, which several ranks use
-                # anyway, so the same input runs on every world size.
+            if init is None:
+                # 'spectral'.  The whole block power iteration stays on the device -- on one
+                # rank, and on several once they have their exchange (peer arenas or the
+                # library's communicator: the per-rank products are then summed where they
+                # are).  Its Cholesky-QR needs an iterate of full column rank; maps it cannot
+                # take -- fewer than 4 bins (centring leaves at most 2 directions), an empty
+                # or unconstrained map -- and transports that sum on the host (gloo, torch)
+                # go through the host-driven form below, so the same input runs everywhere.
                 v0 = numpy.random.default_rng(self.seed).standard_normal((n, 3))
-                try:
-                    eng.spectral_init_device(40, v0)
-                    on_device = True
-                except RuntimeError:
-                    pass
+                if world > 1:
+                    eng.set_coords(v0)             # (a trial in select_exchange wants a start)
+                    select_exchange(eng, lr)
+                device_form = hasattr(eng, "spectral_init_device") and n >= 4 and (
+                    world == 1 or getattr(eng, "_comm_state", None) in ("peer", "rccl"))
+                if device_form:
+                    try:
+                        eng.spectral_init_device(40, v0)
+                        on_device = True
+                    except RankDeficient:
+                        pass
+                    if world > 1:
+                        if getattr(eng, "_comm_state", None) == "peer":
+                            eng.peer_status()
+                        on_device = _all_ranks(on_device)
             if not on_device:
-                if init is None:                   # 'spectral', several ranks / test engines
+                if init is None:                   # 'spectral', host-driven
                     init = spectral_init(eng, n, world, seed=self.seed)
                 eng.set_coords(init)
             if self.momentum:
@@ -732,10 +755,17 @@ def spectral_init(eng, n, world, n_iter=40, seed=0):
                 dist.all_reduce(t)
         return -0.5 * (W - W.mean(axis=0))
 
+    def orth(A):
+        # fewer than 3 bins: QR gives fewer than 3 columns; the missing ones are zero directions
+        Q = numpy.linalg.qr(A)[0]
+        if Q.shape[1] < 3:
+            Q = numpy.hstack([Q, numpy.zeros((n, 3 - Q.shape[1]))])
+        return Q
+
     G0 = numpy.random.default_rng(seed).standard_normal((n, 3))
-    V = numpy.linalg.qr(G0)[0]
+    V = orth(G0)
     for _ in range(int(n_iter)):
-        V = numpy.linalg.qr(apply_B(V))[0]
+        V = orth(apply_B(V))
     Z = apply_B(V)
     evals, evecs = numpy.linalg.eigh(0.5 * (V.T @ Z + Z.T @ V))       # Rayleigh-Ritz, 3x3
     order = numpy.argsort(evals)[::-1]

@@ -270,13 +270,20 @@ BB_API int bb_solver_write_exchange(bb_solver *s, const double *host, int64_t n)
  * ContactMap.eigenvector (blueberry/datatypes.pyx:216-235). */
 BB_API int bb_solver_matvec_sq(bb_solver *s, const double *x, double *y);
 
-/* Classical-MDS start computed and LEFT on the device (one rank): `n_iter` block power
- * iterations on B = -1/2 J (D o D) J over the resident units (one sweep each, as
- * bb_solver_matvec_sq) from the (n_bins,3) host start `v0`, Cholesky-QR between them, a
- * 3 x 3 Rayleigh-Ritz step, X0 = V sqrt(Lambda) written straight into the solver's
- * coordinates (history and velocity reset, as bb_solver_set_coords).  Only 12 doubles per
- * step cross PCIe.  The role SURVEY.md 8(f)-2 gives ContactMap.eigenvector as the solver's
- * initialisation (blueberry/datatypes.pyx:216-235). */
+/* Classical-MDS start computed and LEFT on the device: `n_iter` block power iterations on
+ * B = -1/2 J (D o D) J over the resident units (one sweep each, as bb_solver_matvec_sq) from
+ * the (n_bins,3) host start `v0`, Cholesky-QR between them, a 3 x 3 Rayleigh-Ritz step,
+ * X0 = V sqrt(Lambda) written straight into the solver's coordinates (history and velocity
+ * reset, as bb_solver_set_coords).  The N x 3 algebra of the loop -- centring, Gram matrices,
+ * the 3 x 3 Cholesky factors and the maps they define -- runs in kernels that hand their
+ * results to one another in device memory: no host round trip per product, three reads of
+ * 12 doubles for the whole start.  world > 1: collective; every rank passes the same v0, the
+ * per-rank products are summed over the ranks on the device through the exchange the solver
+ * already has (bb_solver_peer_connect, or bb_solver_comm_init / _attach; BB_ERR_STATE without
+ * one), and every rank ends with the same coordinates.  BB_ERR_STATE "lost rank" when the
+ * iterate has fewer than 3 independent directions (coordinates untouched).  The role
+ * SURVEY.md 8(f)-2 gives ContactMap.eigenvector as the solver's initialisation
+ * (blueberry/datatypes.pyx:216-235). */
 BB_API int bb_solver_spectral_init(bb_solver *s, int n_iter, const double *v0);
 
 /* Stress of the current coordinates (one gradient pass, no update). */

@@ -85,6 +85,90 @@ def test_sharded_solve_equals_single_process_oracle(oracle, world, dtype):
         assert numpy.array_equal(X, results[0][1]) and numpy.array_equal(hist, results[0][2])
 
 
+# ---- init='spectral' on several ranks: which form runs, and that the ranks agree --------
+def _spectral_worker(rank, world, port, n, fail_rank, q):
+    """fit(init='spectral') on `world` gloo ranks with an engine that HAS a device-resident
+    start and a transport that sums on the device (played: _comm_state = 'peer').  The
+    device form must be tried after the exchange is chosen, and if it is refused anywhere
+    (RankDeficient on `fail_rank`) EVERY rank must take the host-driven start."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import blueberry_amd as bb
+        from blueberry_amd import solver
+        from tests import _oracle
+        from tests._engines import OracleEngine
+
+        log = []
+        host_form = solver.spectral_init
+
+        def counted_host_form(*a, **k):
+            log.append("host")
+            return host_form(*a, **k)
+
+        class Eng(OracleEngine):
+            def spectral_init_device(self, n_iter, v0):
+                assert self._comm_state == "peer", "the exchange must be chosen first"
+                log.append("device")
+                x = host_form(self, self.n_bins, self.world, n_iter=n_iter, seed=0)   # collective
+                if rank == fail_rank:
+                    raise solver.RankDeficient("the iterate lost rank (scripted)")
+                self.set_coords(x)
+
+            def peer_status(self):
+                return 0
+
+            def iterate_peer(self, k, lr):
+                for _ in range(k):
+                    self.grad()
+                    solver.allreduce_exchange_host(self)
+                    self.apply(lr)
+
+        def fake_select(eng, lr, trial=False):
+            eng._comm_state = "peer"
+            return "peer"
+
+        solver.select_exchange = fake_select
+        solver.spectral_init = counted_host_form
+        xs = _oracle.random_walk(n)
+        w = _oracle.wish_from_coords(xs)
+        s = bb.StructureSolver(n_iter=2, dtype="float64", kind="wish", engine=Eng,
+                               init="spectral").fit(w)
+        q.put((rank, log, s.structure_, s.stress_))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, traceback.format_exc(), None, None))
+
+
+@pytest.mark.parametrize("fail_rank", [None, 1])
+def test_multi_rank_spectral_start_control_flow(fail_rank):
+    import torch.multiprocessing as mp
+    from tests import _oracle
+    n, world = 300, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_spectral_worker, args=(r, world, port, n, fail_rank, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert not isinstance(r[1], str), r[1]
+        # the device form is tried once everywhere; refused anywhere -> host form everywhere
+        assert r[1] == (["device"] if fail_rank is None else ["device", "host"])
+    w = _oracle.wish_from_coords(_oracle.random_walk(n))
+    for rank, _, X, hist in results:
+        assert numpy.abs(_oracle.wish_from_coords(X) - w).max() < 1e-6 * w.max()
+    assert numpy.array_equal(results[0][2], results[1][2])         # replicas identical
+
+
 # ---- select_exchange: the decision logic, with a scripted engine -----------------
 class _ScriptedEngine(object):
     """Stands in for HipEngine: records what select_exchange does to it and lets a

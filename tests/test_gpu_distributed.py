@@ -488,3 +488,84 @@ def test_peer_exchange_call_sequence_errors():
     assert lib.bb_solver_peer_export(None, ha) == _lib.BB_ERR_INVALID
     for e in (a, b, other):
         e.close()
+
+
+class _CountingLib(object):
+    """Wraps the ctypes library of one engine and counts the calls that move an (N, 3) array
+    between host and device."""
+    moving = ("bb_solver_get_coords", "bb_solver_set_coords", "bb_solver_matvec_sq",
+              "bb_solver_read_exchange", "bb_solver_write_exchange")
+
+    def __init__(self, lib):
+        self._lib, self.counts = lib, {}
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name in self.moving:
+            def counted(*a, **k):
+                self.counts[name] = self.counts.get(name, 0) + 1
+                return fn(*a, **k)
+            return counted
+        return fn
+
+
+@pytest.mark.parametrize("form", ["one launch", "two launches"])
+@pytest.mark.parametrize("dtype,tol,world", [("float64", 1e-12, 2), ("float32", 1e-5, 3)])
+def test_multi_rank_spectral_start_stays_on_the_device(dtype, tol, world, form, monkeypatch):
+    """init='spectral' on several ranks.  `world` ranks of this process, their
+    arenas connected, each driven by a thread of its own (the start synchronises at its end;
+    the ranks' kernels meet in the exchange): the per-rank products of the block power
+    iteration are summed through the peer exchange ON THE DEVICE -- no (N, 3) array crosses
+    PCIe inside the loop -- and every rank ends with the start one rank computes alone
+    (same Ritz sign rule), bit-identical among the ranks."""
+    import threading
+    monkeypatch.setenv("BB_PEER_TIMEOUT_MS", "20000")
+    monkeypatch.setenv("BB_PEER_FUSED", "1" if form == "one launch" else "0")
+    from blueberry_amd.solver import HipEngine
+    from tests import _oracle
+    n = 2600                                      # above the row-owner switch for world = 1 too
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    v0 = numpy.random.default_rng(0).standard_normal((n, 3))
+    one = HipEngine(n, dtype)
+    one.set_wish_dense(w, "wish", 3.0)
+    one.spectral_init_device(40, v0)
+    X1 = one.get_coords()
+    one.close()
+    engs = _peer_engines(world, n, dtype, w, v0)
+    assert all(e.peer_form() == form for e in engs)
+    for e in engs:
+        e._lib = _CountingLib(e._lib)
+    errs = []
+
+    def run(e):
+        try:
+            e.spectral_init_device(40, v0)
+        except Exception as exc:                  # noqa: BLE001
+            errs.append(exc)
+
+    threads = [threading.Thread(target=run, args=(e,)) for e in engs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errs, errs
+    for e in engs:
+        assert e.peer_status() == 0
+        assert e._lib.counts == {}, e._lib.counts   # nothing of size N moved during the start
+    Xs = [e.get_coords() for e in engs]
+    for X in Xs:
+        assert numpy.abs(X - X1).max() < tol * numpy.abs(X1).max()
+    for X in Xs[1:]:
+        assert numpy.array_equal(X, Xs[0])
+    # the start is a start: the solver goes on from it over the same exchange
+    lr = 1.0 / (2 * n)
+    for e in engs:
+        e.iterate_peer(3, lr)
+    hs = [e.stress_history() for e in engs]
+    for e in engs:
+        assert e.peer_status() == 0
+        e.close()
+    d = _oracle.wish_from_coords(Xs[0])
+    assert numpy.abs(d - w).max() < (1e-6 if dtype == "float64" else 1e-3) * w.max()
+    assert all(numpy.array_equal(h, hs[0]) for h in hs) and hs[0].shape == (3,)

@@ -190,6 +190,21 @@ def test_spectral_init_host_loop_is_classical_mds():
     assert (x0.T @ p > 0).all()
 
 
+@pytest.mark.parametrize("n", [2, 3])
+def test_spectral_init_on_two_and_three_bins(n):
+    """numpy's QR of a (2, 3) start has 2 columns; the host loop pads the missing
+    direction with zeros, so fit(init='spectral') runs for every n >= 2 and still recovers
+    the pairwise distances (2 or 3 points always embed exactly)."""
+    from tests._engines import OracleEngine
+    from tests import _oracle
+    xs = numpy.random.default_rng(4).standard_normal((n, 3)) * 3.0
+    w = _oracle.wish_from_coords(xs)
+    s = bb.StructureSolver(n_iter=2, dtype="float64", kind="wish", init="spectral",
+                           distributed=False, engine=OracleEngine).fit(w)
+    assert s.structure_.shape == (n, 3) and numpy.isfinite(s.structure_).all()
+    assert numpy.abs(_oracle.wish_from_coords(s.structure_) - w).max() < 1e-9 * w.max()
+
+
 def test_count_band_regions_input_checks():
     with pytest.raises(ValueError):
         bb.band._as_regions(numpy.zeros((2, 2)))
