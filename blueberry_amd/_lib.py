@@ -69,6 +69,8 @@ SIGNATURES = {
     "bb_solver_comm_world": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "bb_solver_comm_abort": (c_int, [c_void_p]),
     "bb_comm_cached": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int)]),
+    "bb_comm_cached_generation": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int),
+                                          ctypes.POINTER(ctypes.c_uint64)]),
     "bb_solver_comm_attach": (c_int, [c_void_p]),
     "bb_solver_comm_detach": (c_int, [c_void_p]),
     "bb_comm_cache_clear": (c_int, []),

@@ -77,6 +77,7 @@ struct bb_solver {
 
     bb::Rccl::Comm comm = nullptr;  // direct RCCL path (bb_solver_comm_init), else null
     bool comm_cached = false;       // the communicator belongs to the process-wide cache
+    bool comm_suspect = false;      // a collective on it failed to enqueue: never handed out again
 
     // peer exchange (bb_solver_peer_*)
     void *peer_arena = nullptr;             // this rank's receive arena (uncached)
@@ -856,9 +857,13 @@ int bb_solver_destroy(bb_solver *s) {
     if (!s->stream_stuck && (s->stream || !s->own_stream)) hipStreamSynchronize(s->stream);
     if (s->comm) {
         bb::Rccl::Comm c = s->comm;
-        const bool cached = s->comm_cached;
-        comm_release(s, /*destroy=*/false);  // a cached communicator goes back to the cache
-        if (!cached) bb::rccl().CommDestroy(c);
+        const bool cached = s->comm_cached, suspect = s->comm_suspect;
+        comm_release(s, /*destroy=*/false);  // a cached communicator goes back to the cache ...
+        if (suspect) {                       // ... unless a collective on it failed: out of the
+            if (bb::rccl().CommAbort) bb::rccl().CommAbort(c);   // cache (comm_release) and ended
+        } else if (!cached) {
+            bb::rccl().CommDestroy(c);
+        }
     }
     for (void *m : s->peer_opened) hipIpcCloseMemHandle(m);
     hipFree(s->peer_arena);
@@ -1179,7 +1184,18 @@ namespace {
 struct CachedComm {
     bb::Rccl::Comm comm = nullptr;
     bool in_use = false;
+    // Which ncclCommInitRank made it: a hash of the 128-byte unique id, the same on every rank
+    // of that call and on no other.  The key (device, rank, world) alone cannot tell two
+    // communicators of different jobs -- or of different generations of one job -- apart; the
+    // ranks compare this before anybody attaches (bb_comm_cached_generation, solver.comm_reuse).
+    uint64_t generation = 0;
 };
+uint64_t comm_generation_of(const void *unique_id) {
+    uint64_t h = 1469598103934665603ull;             // FNV-1a over the id
+    const unsigned char *b = (const unsigned char *)unique_id;
+    for (size_t i = 0; i < bb::kUniqueIdBytes; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    return h ? h : 1;                                // 0 = "none"
+}
 std::mutex g_comm_mu;
 std::map<std::tuple<int, int, int>, CachedComm> g_comm_cache;
 
@@ -1189,7 +1205,7 @@ void comm_release(bb_solver *s, bool destroy) {
     if (s->comm_cached) {
         auto it = g_comm_cache.find(std::make_tuple(s->device, s->rank, s->world));
         if (it != g_comm_cache.end() && it->second.comm == s->comm) {
-            if (destroy)
+            if (destroy || s->comm_suspect)
                 g_comm_cache.erase(it);       // a suspect communicator is not handed out again
             else
                 it->second.in_use = false;
@@ -1197,8 +1213,21 @@ void comm_release(bb_solver *s, bool destroy) {
     }
     s->comm = nullptr;
     s->comm_cached = false;
+    s->comm_suspect = false;
 }
 }  // namespace
+
+int bb_comm_cached_generation(int device, int rank, int world, int *available,
+                              uint64_t *generation) {
+    BB_REQUIRE(available != nullptr && generation != nullptr,
+               "bb_comm_cached_generation: NULL argument");
+    std::lock_guard<std::mutex> lock(g_comm_mu);
+    auto it = g_comm_cache.find(std::make_tuple(device, rank, world));
+    const bool have = it != g_comm_cache.end() && it->second.comm && !it->second.in_use;
+    *available = have ? 1 : 0;
+    *generation = have ? it->second.generation : 0;
+    return BB_OK;
+}
 
 int bb_comm_cached(int device, int rank, int world, int *available) {
     BB_REQUIRE(available != nullptr, "bb_comm_cached: available is NULL");
@@ -1261,6 +1290,7 @@ int bb_solver_comm_init(bb_solver *s, const void *unique_id) {
             if (c.comm && c.comm != s->comm) R.CommDestroy(c.comm);   // a stale one: replaced
             c.comm = s->comm;
             c.in_use = true;
+            c.generation = comm_generation_of(unique_id);
             s->comm_cached = true;
         }
     }
@@ -1311,8 +1341,10 @@ int enqueue_allreduce(bb_solver *s) {
     const int rc = R.AllReduce(s->d_exch, s->d_exch, (size_t)(3 * s->L.n_pad + 2),
                                s->dtype == BB_F32 ? bb::Rccl::kFloat32 : bb::Rccl::kFloat64,
                                bb::Rccl::kSum, s->comm, s->stream);
-    if (rc != bb::Rccl::kSuccess)
+    if (rc != bb::Rccl::kSuccess) {
+        s->comm_suspect = true;      // its peers may now sit in a collective this rank left
         return bb::fail(BB_ERR_HIP, std::string("ncclAllReduce: ") + R.GetErrorString(rc));
+    }
     return BB_OK;
 }
 }  // namespace

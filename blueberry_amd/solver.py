@@ -224,6 +224,15 @@ class HipEngine(object):
         self._lib.bb_comm_cached(self.device, self.rank, self.world, ctypes.byref(have))
         return bool(have.value)
 
+    def _comm_generation(self):
+        """Generation of the free cached communicator for this engine's key -- a hash of the
+        unique id it was made with, equal on the ranks that made it together -- or 0."""
+        import ctypes
+        have, gen = ctypes.c_int(0), ctypes.c_uint64(0)
+        self._lib.bb_comm_cached_generation(self.device, self.rank, self.world,
+                                            ctypes.byref(have), ctypes.byref(gen))
+        return int(gen.value) if have.value else 0
+
     def _comm_attach(self):
         return self._lib.bb_solver_comm_attach(self._h) == _lib.BB_OK
 
@@ -695,6 +704,16 @@ class StructureSolver(object):
             self.exchange_ = getattr(eng, "_comm_state", None)
             self.structure_ = eng.get_coords()
             self.stress_ = eng.stress_history()
+        except BaseException:
+            # this rank leaves a multi-rank job in the middle: its peers may sit in a collective
+            # on the library's communicator, which must then not go back into the cache for the
+            # next fit() to borrow (close() would return it as free)
+            if getattr(eng, "_comm_state", None) == "rccl" and hasattr(eng, "comm_abort"):
+                try:
+                    eng.comm_abort()
+                except Exception:                  # noqa: BLE001 -- the first error is the one to report
+                    pass
+            raise
         finally:
             eng.close()
         self.n_bins_, self.lr_, self.n_iter_ = n, lr, int(self.stress_.shape[0])
@@ -850,7 +869,17 @@ def comm_reuse(eng):
     Collective, and the same on every rank by construction: the ranks first agree that
     EVERY one of them holds a free cached communicator, then that every attach worked;
     otherwise nobody uses the cache and `comm_setup` makes a fresh one everywhere."""
-    if not _all_ranks(eng._comm_cached()):
+    if hasattr(eng, "_comm_generation"):
+        # ... and that it is the SAME communicator on all of them: the cache is keyed by
+        # (device, rank, world) only, and a rank can hold one of another generation -- made
+        # while a peer's earlier solver still held the previous one, or by an earlier process
+        # group of the same size.  Attaching those would hang the first all-reduce.
+        import torch.distributed as dist
+        gens = [None] * dist.get_world_size()
+        dist.all_gather_object(gens, eng._comm_generation())
+        if gens[0] == 0 or any(g != gens[0] for g in gens):
+            return False
+    elif not _all_ranks(eng._comm_cached()):
         return False
     ok = eng._comm_attach()
     if not _all_ranks(ok):

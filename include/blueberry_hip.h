@@ -202,6 +202,15 @@ BB_API int bb_solver_comm_abort(bb_solver *s);
  *   bb_solver_comm_detach   hand a borrowed one back without using it
  *   bb_comm_cache_clear     destroy the communicators no solver holds (ncclCommDestroy) */
 BB_API int bb_comm_cached(int device, int rank, int world, int *available);
+/* The same with the cached communicator's GENERATION: a hash of the unique id its
+ * ncclCommInitRank was given -- equal on the ranks that made it together, different for any
+ * other communicator of the same (device, rank, world), e.g. one left over from an earlier
+ * process group or made while another rank's solver still held the previous one.  The ranks
+ * must hold the SAME generation before any of them attaches (the Python wrapper all-gathers
+ * it); 0 when nothing is available.  A communicator whose collective failed to enqueue, or
+ * that bb_solver_comm_abort gave up, never returns to the cache. */
+BB_API int bb_comm_cached_generation(int device, int rank, int world, int *available,
+                                     uint64_t *generation);
 BB_API int bb_solver_comm_attach(bb_solver *s);
 BB_API int bb_solver_comm_detach(bb_solver *s);
 BB_API int bb_comm_cache_clear(void);

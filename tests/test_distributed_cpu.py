@@ -403,6 +403,85 @@ def test_two_fits_make_one_communicator():
         assert n3 == 2 and c3 == "made by fit 2"                       # both ranks, not just rank 1
 
 
+def _generation_worker(rank, world, port, q):
+    """every rank answers 'cached and free', but the communicators are of
+    DIFFERENT generations -- rank 0 replaced its stale entry while rank 1's earlier solver
+    still held the old one.  Attaching them would hang the first all-reduce: comm_reuse
+    compares the generations, nobody attaches, every rank makes a fresh one."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.pop("BB_COMM", None)
+        os.environ.pop("BB_COMM_TRIAL", None)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from blueberry_amd import solver
+        from tests._engines import ScriptedRankEngine
+
+        cache = {}
+        attached = []
+
+        class Engine(ScriptedRankEngine):
+            setups = 0
+
+            def comm_setup(self):
+                Engine.setups += 1
+                cache["comm"], cache["gen"] = "made by setup %d" % Engine.setups, 100 + Engine.setups
+                self.comm = cache["comm"]
+                return True
+
+            def _comm_cached(self):
+                return "comm" in cache
+
+            def _comm_generation(self):
+                return cache.get("gen", 0)
+
+            def _comm_attach(self):
+                attached.append(cache["gen"])
+                self.comm = cache["comm"]
+                return True
+
+            def _comm_detach(self):
+                self.comm = None
+
+        dist.get_backend = lambda *a, **k: "nccl"
+        out = []
+        e = Engine(rank, world, None)
+        out.append((solver.select_exchange(e, 0.5), Engine.setups, e.comm))     # fit 1: made
+        e = Engine(rank, world, None)
+        out.append((solver.select_exchange(e, 0.5), Engine.setups, e.comm))     # fit 2: reused
+        if rank == 0:                     # rank 0 now holds a communicator of another generation
+            cache["comm"], cache["gen"] = "someone else's", 7
+        e = Engine(rank, world, None)
+        out.append((solver.select_exchange(e, 0.5), Engine.setups, e.comm))     # fit 3: fresh
+        q.put((rank, out, attached))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "FAILED " + traceback.format_exc(), None))
+
+
+def test_cached_communicators_of_different_generations_are_not_attached():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_generation_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = {r[0]: r for r in (q.get(timeout=120) for _ in procs)}
+    for p in procs:
+        p.join(timeout=30)
+    for rank in (0, 1):
+        assert not isinstance(results[rank][1], str), results[rank][1]
+        (s1, n1, c1), (s2, n2, c2), (s3, n3, c3) = results[rank][1]
+        assert (s1, s2, s3) == ("rccl", "rccl", "rccl")
+        assert (n1, n2) == (1, 1) and c2 == c1                     # same generation: reused
+        assert n3 == 2 and c3 == "made by setup 2"                 # mismatch: fresh on BOTH ranks
+        assert results[rank][2] == [101]                           # the only attach was fit 2's
+
+
 def test_select_exchange_overrides(one_rank_group, monkeypatch):
     from blueberry_amd import solver
     monkeypatch.setattr(one_rank_group, "get_backend", lambda *a, **k: "nccl")
