@@ -49,6 +49,10 @@ SIGNATURES = {
     "bb_solver_set_wish_dense": (c_int, [c_void_p, p_dbl, c_i64, c_int, c_dbl]),
     "bb_solver_set_wish_sparse": (c_int, [c_void_p, p_i64, p_i64, p_dbl, c_i64, c_int, c_dbl,
                                           p_dbl, p_dbl]),
+    "bb_triples_create": (c_int, [ctypes.POINTER(c_void_p), p_dbl, c_i64, c_i32, c_i32, c_int]),
+    "bb_triples_destroy": (c_int, [c_void_p]),
+    "bb_triples_tiles": (c_int, [c_void_p, c_i64, c_int, ctypes.POINTER(ctypes.c_uint8), c_i64]),
+    "bb_solver_set_wish_triples": (c_int, [c_void_p, c_void_p, c_int, c_dbl, p_dbl, p_dbl]),
     "bb_solver_set_wish_from_coords": (c_int, [c_void_p, p_dbl]),
     "bb_solver_set_coords": (c_int, [c_void_p, p_dbl]),
     "bb_solver_get_coords": (c_int, [c_void_p, p_dbl]),

@@ -998,10 +998,11 @@ int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *
                 e = hipMemcpyAsync(d_vals, vals + k0, (size_t)m * 8, hipMemcpyHostToDevice, s->stream);
             if (e != hipSuccess) break;
             const unsigned grid = (unsigned)((m + 255) / 256);
+            const EntrySrc src = {d_rows, d_cols, d_vals, nullptr, 0, 0, 1.0};
 #define BB_SCATTER(TT, WW, PH)                                                                  \
-    bb::launch(scatter_entries_kernel<TT, WW>, dim3(grid), dim3(256), 0, s->stream, d_rows, d_cols, \
-               d_vals, m, d_map, nb, s->L.n_bins, s->u_begin, s->u_end, (TT *)s->d_units, kind,    \
-               -1.0 / alpha, d_kr, d_ke, d_bad, PH)
+    bb::launch(scatter_entries_kernel<TT, WW>, dim3(grid), dim3(256), 0, s->stream, src, m, d_map, \
+               nb, s->L.n_bins, s->u_begin, s->u_end, (TT *)s->d_units, kind, -1.0 / alpha, d_kr,  \
+               d_ke, d_bad, PH)
             // clear / find the last entry per cell / store it (later chunks simply
             // repeat this on top of earlier ones, so "last wins" holds across chunks)
             for (int ph = 0; ph < 3 && e == hipSuccess; ++ph) {
@@ -1031,6 +1032,140 @@ int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *
         return bb::fail(BB_ERR_INVALID,
                         "bb_solver_set_wish_sparse: an entry falls in a tile that is not in the "
                         "solver's tile list");
+    BB_TRY(refresh_full(s));
+    s->have_wish = true;
+    return BB_OK;
+}
+
+// ---- Rao-format triples resident on the device (fit_triples without host binning) --------
+struct bb_triples {
+    int device = 0;
+    int64_t n = 0, st = 3, sc = 1;      // element (t, c) at d[t * st + c * sc]
+    double resolution = 1.0;
+    double *d = nullptr;
+};
+
+int bb_triples_create(bb_triples **out, const double *triples, int64_t n, int32_t resolution,
+                      int32_t row_major, int device) {
+    BB_REQUIRE(out != nullptr, "bb_triples_create: out is NULL");
+    *out = nullptr;
+    BB_REQUIRE(n >= 0 && (n == 0 || triples != nullptr), "bb_triples_create: NULL triples");
+    BB_REQUIRE(resolution > 0, "bb_triples_create: resolution must be positive");
+    BB_TRY(bb::use_device(device));
+    bb_triples *t = new (std::nothrow) bb_triples();
+    if (!t) return bb::fail(BB_ERR_NOMEM, "bb_triples_create: out of host memory");
+    t->device = device;
+    t->n = n;
+    t->resolution = (double)resolution;
+    if (row_major) { t->st = 3; t->sc = 1; } else { t->st = 1; t->sc = n; }
+    int rc = dev_alloc(&t->d, 3 * n);
+    if (rc == BB_OK && n > 0) {
+        const hipError_t e = hipMemcpy(t->d, triples, (size_t)n * 24, hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+            rc = bb::fail(BB_ERR_HIP, std::string("bb_triples_create: ") + hipGetErrorString(e));
+    }
+    if (rc != BB_OK) {
+        hipFree(t->d);
+        delete t;
+        return rc;
+    }
+    *out = t;
+    return BB_OK;
+}
+
+int bb_triples_destroy(bb_triples *t) {
+    if (!t) return BB_OK;
+    hipSetDevice(t->device);
+    hipFree(t->d);
+    delete t;
+    (void)hipGetLastError();
+    return BB_OK;
+}
+
+int bb_triples_tiles(const bb_triples *t, int64_t n_bins, int dtype, uint8_t *present,
+                     int64_t n_blocks) {
+    BB_REQUIRE(t != nullptr && present != nullptr, "bb_triples_tiles: NULL argument");
+    bb_layout_info L;
+    BB_TRY(bb_layout_dense_info(n_bins, dtype, &L));
+    BB_REQUIRE(n_blocks == L.n_blocks, "bb_triples_tiles: present must hold n_blocks^2 bytes of "
+                                       "the layout of (n_bins, dtype)");
+    BB_TRY(bb::enter_device(t->device));
+    bb::DevBuf bp, bb_;
+    if (bp.alloc((size_t)(n_blocks * n_blocks)) != hipSuccess || bb_.alloc(sizeof(int)) != hipSuccess)
+        return bb::fail(BB_ERR_NOMEM, "bb_triples_tiles: out of device memory");
+    BB_HIP_CHECK(hipMemset(bp.p, 0, (size_t)(n_blocks * n_blocks)));
+    BB_HIP_CHECK(hipMemset(bb_.p, 0, sizeof(int)));
+    constexpr int64_t kChunk = (int64_t)1 << 30;
+    for (int64_t k0 = 0; k0 < t->n; k0 += kChunk) {
+        const int64_t m = std::min(kChunk, t->n - k0);
+        const EntrySrc src = {nullptr, nullptr, nullptr, t->d + k0 * (t->st == 3 ? 3 : 1), t->st, t->sc,
+                              t->resolution};
+        BB_HIP_CHECK(bb::launch(entries_tiles_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0,
+                                (hipStream_t) nullptr, src, m, L.vw, n_blocks, n_bins,
+                                (unsigned char *)bp.p, (int *)bb_.p));
+    }
+    int bad = 0;
+    BB_HIP_CHECK(hipMemcpy(&bad, bb_.p, sizeof(int), hipMemcpyDeviceToHost));
+    BB_HIP_CHECK(hipMemcpy(present, bp.p, (size_t)(n_blocks * n_blocks), hipMemcpyDeviceToHost));
+    if (bad) return bb::fail(BB_ERR_INVALID, "bb_triples_tiles: an index is outside [0, n_bins)");
+    return BB_OK;
+}
+
+int bb_solver_set_wish_triples(bb_solver *s, const bb_triples *t, int kind, double alpha,
+                               const double *KRnorm, const double *KRexpected) {
+    BB_REQUIRE(s != nullptr && t != nullptr, "bb_solver_set_wish_triples: NULL argument");
+    BB_REQUIRE(kind == BB_KIND_WISH || kind == BB_KIND_COUNTS, "bb_solver_set_wish_triples: bad kind");
+    BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_triples: alpha must be > 0");
+    BB_REQUIRE((KRnorm == nullptr) == (KRexpected == nullptr),
+               "bb_solver_set_wish_triples: KRnorm and KRexpected go together");
+    BB_REQUIRE(t->device == s->device,
+               "bb_solver_set_wish_triples: the triples live on another device than the solver");
+    BB_TRY(bb::enter_device(s->device));
+    const int64_t nb = s->L.n_blocks;
+    std::vector<int32_t> tilemap((size_t)(nb * nb), -1);
+    for (size_t q = 0; q < s->tile_I.size(); ++q)
+        tilemap[(size_t)s->tile_I[q] * nb + s->tile_J[q]] = (int32_t)q;
+    bb::DevBuf bmap, bbad, bkr, bke;
+    if (bmap.alloc((size_t)(nb * nb) * 4) != hipSuccess || bbad.alloc(sizeof(int)) != hipSuccess ||
+        (KRnorm && (bkr.alloc((size_t)s->L.n_bins * 8) != hipSuccess ||
+                    bke.alloc((size_t)s->L.n_bins * 8) != hipSuccess)))
+        return bb::fail(BB_ERR_NOMEM, "bb_solver_set_wish_triples: out of device memory");
+    hipStream_t st = s->stream;
+    BB_HIP_CHECK(hipMemcpyAsync(bmap.p, tilemap.data(), tilemap.size() * 4, hipMemcpyHostToDevice, st));
+    if (KRnorm) {
+        BB_HIP_CHECK(hipMemcpyAsync(bkr.p, KRnorm, (size_t)s->L.n_bins * 8, hipMemcpyHostToDevice, st));
+        BB_HIP_CHECK(hipMemcpyAsync(bke.p, KRexpected, (size_t)s->L.n_bins * 8, hipMemcpyHostToDevice, st));
+    }
+    BB_HIP_CHECK(hipMemsetAsync(bbad.p, 0, sizeof(int), st));
+    BB_HIP_CHECK(hipMemsetAsync(s->d_units, 0, (size_t)std::max<int64_t>(s->n_local, 1) * bb::kUnitBytes, st));
+    // chunks of 2^30 entries: an fp32 cell holds the index of the entry that wins it in 32 bits;
+    // later chunks run on top of earlier ones, so "the last entry wins" holds across them
+    constexpr int64_t kChunk = (int64_t)1 << 30;
+    for (int64_t k0 = 0; k0 < t->n; k0 += kChunk) {
+        const int64_t m = std::min(kChunk, t->n - k0);
+        const EntrySrc src = {nullptr, nullptr, nullptr, t->d + k0 * (t->st == 3 ? 3 : 1), t->st, t->sc,
+                              t->resolution};
+        const unsigned grid = (unsigned)((m + 255) / 256);
+        for (int ph = 0; ph < 3; ++ph) {
+#define BB_SCATTER_T(TT, WW)                                                                       \
+    BB_HIP_CHECK(bb::launch(scatter_entries_kernel<TT, WW>, dim3(grid), dim3(256), 0, st, src, m,   \
+                            (const int32_t *)bmap.p, nb, s->L.n_bins, s->u_begin, s->u_end,        \
+                            (TT *)s->d_units, kind, -1.0 / alpha, (const double *)bkr.p,            \
+                            (const double *)bke.p, (int *)bbad.p, ph))
+            if (s->dtype == BB_F32) BB_SCATTER_T(float, true);
+            else if (s->wide) BB_SCATTER_T(double, true);
+            else BB_SCATTER_T(double, false);
+#undef BB_SCATTER_T
+        }
+    }
+    BB_HIP_CHECK(hipStreamSynchronize(st));
+    int bad = 0;
+    BB_HIP_CHECK(hipMemcpy(&bad, bbad.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (bad == 1)
+        return bb::fail(BB_ERR_INVALID, "bb_solver_set_wish_triples: an index is outside [0, n_bins)");
+    if (bad == 2)
+        return bb::fail(BB_ERR_INVALID, "bb_solver_set_wish_triples: an entry falls in a tile that is "
+                                        "not in the solver's tile list");
     BB_TRY(refresh_full(s));
     s->have_wish = true;
     return BB_OK;

@@ -1883,10 +1883,52 @@ __global__ __launch_bounds__(256) void pack_units_from_matrix_kernel(
 // matrix: `phase` 0 clears every cell an entry names, 1 records the highest entry
 // index + 1 per cell (integer atomicMax on the cell's own bits, which the clear left
 // at 0), 2 lets that entry alone store its value.
+// Where the entries come from: (rows, cols, vals) arrays, or -- `tr` set -- the (n, 3) triples
+// [pos_i, pos_j, count] of a Rao-format file as ContactMap.__init__ reads them
+// (blueberry/datatypes.pyx:100-113), resident on the device: numpy.nan_to_num applied to each
+// value as it is read (pyx:102), bin = (int)(pos / resolution) (pyx:111-112), element (t, c)
+// at tr[t * st + c * sc] (row-major rows or the reference's column-major array).
+struct EntrySrc {
+    const int64_t *rows, *cols;
+    const double *vals;
+    const double *tr;
+    int64_t st, sc;
+    double resolution;
+};
+__device__ __forceinline__ double nan_to_num_f64(double v) {
+    return v != v ? 0.0 : (v > 1.7976931348623157e308 ? 1.7976931348623157e308
+                                                      : (v < -1.7976931348623157e308 ? -1.7976931348623157e308 : v));
+}
+// the entry's bin pair; false: a position outside what an int can hold
+__device__ __forceinline__ bool entry_bins(const EntrySrc &src, int64_t k, int64_t &i, int64_t &j) {
+    if (src.tr == nullptr) { i = src.rows[k]; j = src.cols[k]; return true; }
+    const double qi = nan_to_num_f64(src.tr[k * src.st]) / src.resolution,
+                 qj = nan_to_num_f64(src.tr[k * src.st + src.sc]) / src.resolution;
+    if (!(qi > -2147483648.0 && qi < 2147483648.0 && qj > -2147483648.0 && qj < 2147483648.0))
+        return false;
+    i = (int)qi; j = (int)qj;
+    return true;
+}
+
+// Which tiles the entries name: present[I * n_blocks + J] = 1 (I <= J), so that the host can
+// write down the tile list of a blocked-sparse solver without binning the entries itself.
+__global__ __launch_bounds__(256) void entries_tiles_kernel(EntrySrc src, int64_t nnz, int64_t vw,
+                                                            int64_t n_blocks, int64_t n_bins,
+                                                            unsigned char *__restrict__ present,
+                                                            int *__restrict__ bad) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nnz) return;
+    int64_t i, j;
+    if (!entry_bins(src, k, i, j)) { atomicExch(bad, 1); return; }
+    if (i == j) return;
+    if (i > j) { const int64_t t = i; i = j; j = t; }
+    if (i < 0 || j >= n_bins) { atomicExch(bad, 1); return; }
+    present[(i / vw) * n_blocks + j / vw] = 1;
+}
+
 template <typename T, bool W>
 __global__ __launch_bounds__(256) void scatter_entries_kernel(
-    const int64_t *__restrict__ rows, const int64_t *__restrict__ cols,
-    const double *__restrict__ vals, int64_t nnz, const int32_t *__restrict__ tilemap,
+    EntrySrc src, int64_t nnz, const int32_t *__restrict__ tilemap,
     int64_t n_blocks, int64_t n_bins, int64_t u_begin, int64_t u_end, T *__restrict__ units,
     int kind, double neg_inv_alpha, const double *__restrict__ kr,
     const double *__restrict__ krexp, int *__restrict__ bad, int phase) {
@@ -1894,7 +1936,8 @@ __global__ __launch_bounds__(256) void scatter_entries_kernel(
     using Bits = typename std::conditional<sizeof(T) == 4, unsigned int, unsigned long long>::type;
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= nnz) return;
-    int64_t i = rows[k], j = cols[k];
+    int64_t i, j;
+    if (!entry_bins(src, k, i, j)) { atomicExch(bad, 1); return; }
     if (i == j) return;                     // the diagonal carries no pair
     if (i > j) { const int64_t t = i; i = j; j = t; }
     if (i < 0 || j >= n_bins) { atomicExch(bad, 1); return; }
@@ -1914,7 +1957,7 @@ __global__ __launch_bounds__(256) void scatter_entries_kernel(
         return;
     }
     if (*reinterpret_cast<const Bits *>(cell) != (Bits)(k + 1)) return;   // a later entry won
-    double v = vals[k];
+    double v = src.tr ? nan_to_num_f64(src.tr[k * src.st + 2 * src.sc]) : src.vals[k];
     // KR balancing + observed/expected, the element-wise form of the loop at
     // reference datatypes.pyx:166-169 (same operation order)
     if (kr != nullptr) v = v / (kr[i] * kr[j] * krexp[j - i]);

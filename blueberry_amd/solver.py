@@ -27,6 +27,53 @@ class RankDeficient(RuntimeError):
     `fit()` then takes the host-driven start; every other library error propagates."""
 
 
+class DeviceTriples(object):
+    """The (n, 3) array [pos_i, pos_j, count] of a Rao-format file -- what
+    `ContactMap.__init__` reads (`blueberry/datatypes.pyx:100-102`) -- copied to the device
+    once (`bb_triples_*`): nan_to_num, binning and the scatter into the solver's tiles all
+    happen there.  C-ordered rows and the reference's column-major array are read in place."""
+    is_triples = True
+
+    def __init__(self, triples, resolution, device):
+        t = numpy.asarray(triples, dtype=numpy.float64)
+        if t.ndim != 2 or t.shape[1] != 3:
+            raise ValueError("triples must have shape (n, 3)")
+        if t.flags.c_contiguous:
+            buf, row_major = t, 1
+        elif t.flags.f_contiguous:
+            buf, row_major = t.T, 0
+        else:
+            buf, row_major = numpy.ascontiguousarray(t), 1
+        self._lib = _lib.load()
+        self._h = _lib.c_void_p()
+        self.n, self.device = int(t.shape[0]), int(device)
+        _lib.check(self._lib.bb_triples_create(self._h, _lib.as_f64_ptr(buf), self.n,
+                                               int(resolution), row_major, self.device),
+                   "bb_triples_create")
+
+    def tiles(self, n_bins, dtype):
+        """(tile_I, tile_J), device order, of the tiles the triples name."""
+        import ctypes
+        nb = layout_info(n_bins, dtype)["n_blocks"]
+        present = numpy.zeros((nb, nb), dtype=numpy.uint8)
+        _lib.check(self._lib.bb_triples_tiles(self._h, int(n_bins), _DTYPES[dtype],
+                                              present.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                              nb), "bb_triples_tiles")
+        tj, ti = numpy.nonzero(present.T)            # J ascending, then I
+        return ti.astype(numpy.int32), tj.astype(numpy.int32)
+
+    def close(self):
+        if self._h:
+            self._lib.bb_triples_destroy(self._h)
+            self._h = _lib.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipEngine(object):
     """One rank's device state: thin, 1:1 over the bb_solver_* C-ABI."""
 
@@ -105,6 +152,19 @@ class HipEngine(object):
             _lib.as_f64_ptr(v), r.shape[0], _KINDS[kind], float(alpha),
             None if kr is None else _lib.as_f64_ptr(kr),
             None if ke is None else _lib.as_f64_ptr(ke)), "bb_solver_set_wish_sparse")
+
+    def set_wish_triples(self, dev_triples, kind, alpha, KRnorm=None, KRexpected=None):
+        """From triples resident on the device (`DeviceTriples`): binned, KR / O-E
+        normalised and converted there."""
+        kr = ke = None
+        if KRnorm is not None or KRexpected is not None:
+            if KRnorm is None or KRexpected is None:
+                raise ValueError("KRnorm and KRexpected go together")
+            kr, ke = _pad_vector(KRnorm, self.n_bins), _pad_vector(KRexpected, self.n_bins)
+        _lib.check(self._lib.bb_solver_set_wish_triples(
+            self._h, dev_triples._h, _KINDS[kind], float(alpha),
+            None if kr is None else _lib.as_f64_ptr(kr),
+            None if ke is None else _lib.as_f64_ptr(ke)), "bb_solver_set_wish_triples")
 
     def set_wish_from_coords(self, xstar):
         x = _check_coords(xstar, self.n_bins)
@@ -620,6 +680,7 @@ class StructureSolver(object):
 
     def _fit_impl(self, matrix, n, init, KRnorm, KRexpected):
         resident = getattr(matrix, "is_resident", False)
+        triples = getattr(matrix, "is_triples", False)
         sparse = hasattr(matrix, "row") and not resident
         if n < 2:
             raise ValueError("need at least 2 bins (the contact map is empty)" if n == 0 else
@@ -635,6 +696,8 @@ class StructureSolver(object):
             keep = matrix.row != matrix.col
             rows, cols, vals = matrix.row[keep], matrix.col[keep], matrix.data[keep]
             tiles = tiles_from_entries(n, rows, cols, self.dtype)
+        elif triples:
+            tiles = matrix.tiles(n, self.dtype)
         eng = self._engine_factory(n, self.dtype, rank=rank, world=world,
                                    device=self._pick_device(world), tiles=tiles)
         try:
@@ -646,6 +709,8 @@ class StructureSolver(object):
                     # the map lives on another GPU than this rank's solver (a ContactMap made
                     # with an explicit device): through the host once, like a plain matrix
                     eng.set_wish_dense(matrix.to_host(), self.kind, self.alpha)
+            elif triples:
+                eng.set_wish_triples(matrix, self.kind, self.alpha, KRnorm, KRexpected)
             elif sparse:
                 eng.set_wish_sparse(rows, cols, vals, self.kind, self.alpha, KRnorm, KRexpected)
             else:
@@ -728,16 +793,27 @@ class StructureSolver(object):
         balanced and O/E-normalised on the device as `ContactMap.normalize`
         would (pyx:166-169).  A bin pair that occurs more than once keeps its last
         count, as in the reference's scatter (pyx:115-116)."""
+        n = int(n_bins) + 1
+        if KRnorm is not None and (numpy.any(numpy.asarray(KRnorm) == 0.0)
+                                   or numpy.any(numpy.asarray(KRexpected)[:n_bins] == 0.0)):
+            raise ZeroDivisionError("float division")      # as ContactMap.normalize
+        if hasattr(self._engine_factory, "set_wish_triples"):
+            # nan_to_num (pyx:102), the binning and the tile occupancy on the device: the host
+            # never makes a pass over the triples (round 3: two isfinite passes, two divide +
+            # astype passes and a scipy COO over 240 MB at chr1@10kb)
+            _, world = _dist_state(self.distributed)
+            dev = DeviceTriples(triples, resolution, self._pick_device(world))
+            try:
+                return self._fit_impl(dev, n, init, KRnorm, KRexpected)
+            finally:
+                dev.close()
+        # engines without a device (tests): bin on the host, as round 3 did
         from .datatypes import _nan_to_num
         t = _nan_to_num(triples)          # pyx:102 (no copy when every value is finite)
         if t.ndim != 2 or t.shape[1] != 3:
             raise ValueError("triples must have shape (n, 3)")
-        n = int(n_bins) + 1
         rows = (t[:, 0] / resolution).astype(numpy.int64)
         cols = (t[:, 1] / resolution).astype(numpy.int64)
-        if KRnorm is not None and (numpy.any(numpy.asarray(KRnorm) == 0.0)
-                                   or numpy.any(numpy.asarray(KRexpected)[:n_bins] == 0.0)):
-            raise ZeroDivisionError("float division")      # as ContactMap.normalize
         import scipy.sparse
         keep = rows != cols
         sp = scipy.sparse.coo_matrix((t[keep, 2], (rows[keep], cols[keep])), shape=(n, n))

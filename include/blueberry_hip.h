@@ -143,6 +143,24 @@ BB_API int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld
 BB_API int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *cols,
                                      const double *vals, int64_t nnz, int kind, double alpha,
                                      const double *KRnorm, const double *KRexpected);
+/* The same input WITHOUT host-side binning: the (n, 3) float64 array [pos_i, pos_j, count] of a
+ * Rao-format file exactly as ContactMap.__init__ holds it (blueberry/datatypes.pyx:100-102),
+ * copied to the device once.  row_major != 0: C-ordered (n, 3) rows; 0: the reference's
+ * column-major array (pyx:111-113 read it that way).  numpy.nan_to_num (pyx:102) and
+ * bin = (int)(pos / resolution) (pyx:111-112) are applied by the kernels as they read.
+ *   bb_triples_tiles            which tiles of the (n_bins, dtype) layout the triples name:
+ *                               present[I * n_blocks + J] = 1, I <= J (n_blocks^2 bytes) -- the
+ *                               tile list to create the solver with
+ *   bb_solver_set_wish_triples  as bb_solver_set_wish_sparse (last entry of a pair wins,
+ *                               KRnorm / KRexpected optional), from the resident triples */
+typedef struct bb_triples bb_triples;
+BB_API int bb_triples_create(bb_triples **out, const double *triples, int64_t n, int32_t resolution,
+                             int32_t row_major, int device);
+BB_API int bb_triples_destroy(bb_triples *t);
+BB_API int bb_triples_tiles(const bb_triples *t, int64_t n_bins, int dtype, uint8_t *present,
+                            int64_t n_blocks);
+BB_API int bb_solver_set_wish_triples(bb_solver *s, const bb_triples *t, int kind, double alpha,
+                                      const double *KRnorm, const double *KRexpected);
 /* Synthetic input generated on the device: delta_ij = |x*_i - x*_j| for the
  * (n_bins,3) float64 host coordinates `xstar`, so that
  * N = 50k needs no 20 GB host matrix. */

@@ -929,6 +929,45 @@ def test_fit_triples_repeated_pairs_last_entry_wins(oracle, solver_path):
         assert _rel(direct.structure_, X_ref) < tol, dtype
 
 
+def test_fit_triples_bins_and_cleans_on_the_device(oracle):
+    """fit_triples makes no pass over the triples on the host any
+    more -- nan_to_num (pyx:102), bin = int(pos / resolution) (pyx:111-112) and the tile
+    occupancy are the device's.  NaN / inf counts and positions off the bin grid, in C order
+    and in the reference's column-major layout, give what the ContactMap pipeline gives
+    (which holds them to the reference's golden scatter); a position outside the map raises."""
+    rng = numpy.random.default_rng(33)
+    n_bins, res, k = 1300, 5000, 3
+    m = 50000
+    bi = rng.integers(0, n_bins, m)
+    bj = numpy.minimum(n_bins - 1, bi + rng.geometric(0.01, m))
+    pos_i = bi * float(res) + rng.integers(0, res, m)          # anywhere inside the bin
+    pos_j = bj * float(res) + rng.integers(0, res, m)
+    counts = rng.integers(1, 300, m).astype(float)
+    counts[rng.random(m) < 0.01] = numpy.nan                   # -> 0: no constraint
+    counts[rng.random(m) < 0.01] = numpy.inf                   # -> 1.8e308: delta flushed / tiny
+    triples = numpy.stack([pos_i, pos_j, counts], 1)
+    n = n_bins + 1
+    x0 = numpy.random.default_rng(3).standard_normal((n, 3))
+    lr = 1.0 / (2 * n)
+    cm = bb.ContactMap.from_triples(triples, res, n_bins)
+    for dtype, tol in (("float64", 1e-12), ("float32", 1e-5)):
+        ref = bb.StructureSolver(n_iter=k, lr=lr, dtype=dtype).fit(cm, init=x0)
+        for layout in (triples, numpy.asfortranarray(triples), triples[::-1][::-1]):
+            s = bb.StructureSolver(n_iter=k, lr=lr, dtype=dtype).fit_triples(layout, res, n_bins, init=x0)
+            assert numpy.abs(s.stress_ / ref.stress_ - 1).max() < tol, dtype
+            assert _rel(s.structure_, ref.structure_) < tol, dtype
+    wish = oracle.counts_to_wish(oracle.contactmap_scatter(triples, res, n_bins), 3.0)
+    X_ref, h_ref = oracle.solve(wish, x0, k, lr)
+    s = bb.StructureSolver(n_iter=k, lr=lr, dtype="float64").fit_triples(triples, res, n_bins, init=x0)
+    assert numpy.abs(s.stress_ / h_ref - 1).max() < 1e-12 and _rel(s.structure_, X_ref) < 1e-12
+    bad = triples.copy()
+    bad[7, 1] = (n_bins + 5) * float(res)
+    with pytest.raises(ValueError, match="outside"):
+        bb.StructureSolver(n_iter=1).fit_triples(bad, res, n_bins)
+    with pytest.raises(ValueError):
+        bb.StructureSolver(n_iter=1).fit_triples(triples[:, :2], res, n_bins)
+
+
 # ---- the two remaining numeric helpers of blueberry.pyx ---------------------------
 @pytest.mark.parametrize("k", range(8))         # 4..7: NaN p-values (NaN out, maximum restarts)
 def test_bh_golden_bit_exact(k):
