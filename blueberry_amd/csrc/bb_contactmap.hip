@@ -15,6 +15,8 @@
 #include <math.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "bb_common.h"
@@ -33,8 +35,6 @@ struct bb_cm {
     int sv_items = 0;
     // scratch of bb_cm_correlation (centred rows + Gram matrix), kept between calls: the
     // first touch of a fresh matrix-sized allocation costs 0.2-0.35 s on this platform
-    void *corr_buf = nullptr;
-    size_t corr_bytes = 0;
 };
 
 namespace {
@@ -660,6 +660,45 @@ __global__ __launch_bounds__(256) void center_rows_kernel(const double *__restri
     for (int64_t c = lane; c < d; c += 64) q[c] = p[c] - mean;
 }
 
+// The same in ONE pass (round 4): a workgroup of 1024 threads holds a whole row in registers
+// (CH values per thread, d <= 1024 * CH), adds it up, subtracts the mean and writes it out --
+// 8 B read + 8 B written per element, every load of the row in flight at once.  The two-pass
+// kernel above re-read the 200-KB row for the subtraction (counter traffic x1.50 at d = 24,927)
+// behind one wave's worth of dependent 8-byte loads: 3.15 TB/s.  Also writes the zero padding
+// of the row (columns d .. ldx), so the caller clears only the padding rows.
+template <int CH>
+__global__ __launch_bounds__(1024) void center_rows_reg_kernel(const double *__restrict__ m, int64_t d,
+                                                               double *__restrict__ xc, int64_t ldx) {
+    __shared__ double part[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const double *p = m + row * d;
+    double v[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+        const int64_t c = tid + 1024 * q;
+        v[q] = c < d ? __builtin_nontemporal_load(p + c) : 0.0;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < CH; ++q) acc += v[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) part[wv] = acc;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += part[k];      // every thread, the same order
+    const double mean = tot / (double)d;
+    double *q_out = xc + row * ldx;
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+        const int64_t c = tid + 1024 * q;
+        if (c < d) __builtin_nontemporal_store(v[q] - mean, q_out + c);
+        else if (c < ldx) q_out[c] = 0.0;
+    }
+}
+
 // g (dp x dp) upper tiles = xc xc^T.  Workgroup = one 128 x 128 tile, TI <= TJ; wave =
 // 64 x 64 = 4 x 4 MFMA tiles (128 accumulator VGPRs).  Both operands are rows of xc
 // (K contiguous).  K-tiles of 16 go through LDS as [row][18], double-buffered: while
@@ -898,6 +937,26 @@ __global__ __launch_bounds__(256) void scale_by_kernel(const double *__restrict_
     if (i < d) out[i] = scale[0] * in[i];
 }
 
+// correlation's two matrix-sized temporaries (centred rows, Gram matrix): ONE grow-only
+// allocation per DEVICE, shared by every map on it and guarded by a mutex (calls on one device
+// serialise, as bb_band.hip's context does).  Round 3 kept one per HANDLE for the map's
+// lifetime: a genome-wide loop holding one ContactMap per chromosome then held 3x the
+// matrices' memory.  bb_cm_release_scratch gives it back.
+struct CorrScratch {
+    std::mutex mu;
+    void *buf = nullptr;
+    size_t bytes = 0;
+};
+CorrScratch *corr_scratch(int device) {
+    static std::mutex table_mu;
+    static std::map<int, CorrScratch *> table;
+    std::lock_guard<std::mutex> lock(table_mu);
+    auto it = table.find(device);
+    if (it != table.end()) return it->second;
+    CorrScratch *c = new CorrScratch();   // lives for the process
+    table[device] = c;
+    return c;
+}
 }  // namespace
 
 extern "C" {
@@ -931,7 +990,6 @@ int bb_cm_destroy(bb_cm *cm) {
     bb::release_stream(cm->device, cm->stream);     // synchronises it
     (void)hipFree(cm->m);
     (void)hipFree(cm->sv_buf);
-    (void)hipFree(cm->corr_buf);
     delete cm;
     (void)hipGetLastError();   // tear-down is best effort; its errors end here
     return BB_OK;
@@ -1327,10 +1385,22 @@ int bb_cm_eigenvector(bb_cm *cm, double *vec, double *eigenvalue, double tol, in
     return BB_OK;
 }
 
+int bb_cm_release_scratch(int device) {
+    BB_TRY(bb::enter_device(device));
+    CorrScratch *sc = corr_scratch(device);
+    std::lock_guard<std::mutex> lock(sc->mu);
+    (void)hipFree(sc->buf);
+    sc->buf = nullptr;
+    sc->bytes = 0;
+    return BB_OK;
+}
+
 int bb_cm_correlation(bb_cm *cm, double *tflops) {
     BB_TRY(cm_check(cm, "bb_cm_correlation"));
     const int64_t d = cm->d;
     const int64_t dp = bb::round_up(d, kGT), ldx = bb::round_up(d, kGK);
+    CorrScratch *scr = corr_scratch(cm->device);
+    std::lock_guard<std::mutex> scratch_lock(scr->mu);
     // centred rows | Gram matrix | standard deviations: ONE grow-only allocation kept with
     // the handle.  Round 2 allocated the two matrix-sized temporaries per call, and on this
     // platform the first touch of a fresh block of that size costs 0.17-0.35 s
@@ -1340,25 +1410,39 @@ int bb_cm_correlation(bb_cm *cm, double *tflops) {
     const size_t g_bytes = ((size_t)dp * dp * 8 + 255) & ~(size_t)255;
     const size_t need = xc_bytes + g_bytes + (size_t)d * 8;
     hipError_t e = hipSuccess;
-    if (need > cm->corr_bytes) {
-        (void)hipFree(cm->corr_buf);
-        cm->corr_buf = nullptr;
-        cm->corr_bytes = 0;
-        e = hipMalloc(&cm->corr_buf, need);
-        if (e == hipSuccess) cm->corr_bytes = need;
+    if (need > scr->bytes) {
+        (void)hipFree(scr->buf);
+        scr->buf = nullptr;
+        scr->bytes = 0;
+        e = hipMalloc(&scr->buf, need);
+        if (e == hipSuccess) scr->bytes = need;
     }
     if (e != hipSuccess)
         return bb::fail(BB_ERR_NOMEM, std::string("bb_cm_correlation: ") + hipGetErrorString(e));
-    xc.p = cm->corr_buf;
-    g.p = (char *)cm->corr_buf + xc_bytes;
-    sd.p = (char *)cm->corr_buf + xc_bytes + g_bytes;
+    xc.p = scr->buf;
+    g.p = (char *)scr->buf + xc_bytes;
+    sd.p = (char *)scr->buf + xc_bytes + g_bytes;
     hipStream_t st = cm->stream;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const double fact_inv = 1.0 / (double)(d - 1);   // numpy: true_divide(1, N - ddof); d = 1 -> inf
-    e = hipMemsetAsync(xc.p, 0, (size_t)dp * ldx * 8, st);
-    if (e == hipSuccess)
-        e = bb::launch(center_rows_kernel, dim3((unsigned)((d + 3) / 4)), dim3(256), 0, st,
-                       (const double *)cm->m, d, (double *)xc.p, ldx);
+    // a whole row in the registers of one workgroup where it fits (d <= 32,768); else two passes
+    const int ch = d >= 2048 && d <= 32768 && !getenv("BB_CM_CENTER_OLD") ? (int)((d + 1023) / 1024) : 0;
+    if (ch == 0) {
+        e = hipMemsetAsync(xc.p, 0, (size_t)dp * ldx * 8, st);
+        if (e == hipSuccess)
+            e = bb::launch(center_rows_kernel, dim3((unsigned)((d + 3) / 4)), dim3(256), 0, st,
+                           (const double *)cm->m, d, (double *)xc.p, ldx);
+    } else {
+        // the kernel writes each row's own padding; only the padding ROWS are cleared here
+        if (dp > d) e = hipMemsetAsync((double *)xc.p + d * ldx, 0, (size_t)(dp - d) * ldx * 8, st);
+#define BB_CENTER(CHV)                                                                              \
+    bb::launch(center_rows_reg_kernel<CHV>, dim3((unsigned)d), dim3(1024), 0, st, (const double *)cm->m, \
+               d, (double *)xc.p, ldx)
+        if (e == hipSuccess)
+            e = ch <= 4 ? BB_CENTER(4) : ch <= 8 ? BB_CENTER(8) : ch <= 16 ? BB_CENTER(16)
+              : ch <= 24 ? BB_CENTER(24) : BB_CENTER(32);
+#undef BB_CENTER
+    }
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) e = hipEventRecord(e0, st);

@@ -415,6 +415,10 @@ BB_API int bb_cm_eigenvector(bb_cm *cm, double *vec, double *eigenvalue, double 
  * in numpy's order of operations.  Equal to numpy to rounding (BLAS sums in another
  * order).  tflops (may be NULL): rate of the Gram kernel alone, by HIP events. */
 BB_API int bb_cm_correlation(bb_cm *cm, double *tflops);
+/* bb_cm_correlation's temporaries (centred rows + Gram matrix, about 2x the matrix) live in one
+ * grow-only scratch per device, shared by every map on it; this frees it (it is made again by
+ * the next call that needs it). */
+BB_API int bb_cm_release_scratch(int device);
 /* Hand the resident matrix to a solver of n_bins = d bins on the same device, device
  * to device (same meaning of kind / alpha as bb_solver_set_wish_dense). */
 BB_API int bb_solver_set_wish_from_cm(bb_solver *s, const bb_cm *cm, int kind, double alpha);
