@@ -767,6 +767,9 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__
         const double *qa = pa + buf * (kGT * kGS), *qb = pb + buf * (kGT * kGS);
 #pragma unroll
         for (int kk = 0; kk < kGK / 4; ++kk) {
+#ifdef BB_GRAM_INTERLEAVE
+            if (kk == kGK / 4 - 1) __builtin_amdgcn_sched_barrier(0);
+#endif
             double a[4], b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -779,7 +782,23 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__
                 for (int tb = 0; tb < 4; ++tb)
                     acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
         }
+        // The K-tile in flight goes to LDS BEHIND this tile's 64 MFMAs (4096 cycles of the
+        // matrix pipe: the loads have long landed).  Left alone the scheduler hoists the
+        // stores -- and with them `s_waitcnt vmcnt(0)` -- to four MFMAs below the loads, and
+        // every K-tile then waits out the memory latency with the pipe idle: 58.7 TFLOP/s,
+        // 75 % of the peak (round 3); -DBB_GRAM_NO_SCHED restores that for an A/B.
+#if !defined(BB_GRAM_NO_SCHED) && !defined(BB_GRAM_INTERLEAVE)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         BB_LSTORE(buf ^ 1);
+#ifdef BB_GRAM_INTERLEAVE
+        // (experiment) the eight LDS stores between the last sixteen MFMAs
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
+        }
+#endif
         __syncthreads();
     }
 #undef BB_GLOAD
