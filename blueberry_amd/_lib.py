@@ -113,6 +113,10 @@ SIGNATURES = {
     "bb_cm_correlation": (c_int, [c_void_p, p_dbl]),
     "bb_cm_release_scratch": (c_int, [c_int]),
     "bb_solver_set_wish_from_cm": (c_int, [c_void_p, c_void_p, c_int, c_dbl]),
+    "bb_solver_set_wish_from_cm_block": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_dbl]),
+    "bb_solver_set_maps": (c_int, [c_void_p, c_int, p_i64, p_dbl]),
+    "bb_solver_set_wish_dense_block": (c_int, [c_void_p, p_dbl, c_i64, c_i64, c_i64, c_int, c_dbl]),
+    "bb_solver_stress_maps": (c_int, [c_void_p, p_dbl, c_int]),
     "bb_contactmap_scatter": (c_int, [p_dbl, c_i64, c_i32, p_dbl, c_i64, c_int]),
     "bb_contactmap_normalize": (c_int, [p_dbl, c_i64, p_dbl, p_dbl, c_int]),
     "bb_benjamini_hochberg": (c_int, [p_dbl, c_i64, c_i64, p_dbl, c_int]),

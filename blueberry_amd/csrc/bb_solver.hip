@@ -51,6 +51,15 @@ struct bb_solver {
     int2 *d_wave_slots = nullptr;  // per wave {first private slot, the workgroup's shared slot}
     int lds_wave_floats = 0;       // LDS region per wave of the sweep, in 4-byte words
     double *d_stresspart = nullptr;
+    double *d_stress_slot = nullptr;     // one per column slot: the stress of a strip a wave left
+    std::vector<int32_t> slot_strip;     // strip (block column) of every column slot
+    std::vector<int32_t> wave_last_strip;  // strip each wave ends in, -1: no units
+    // several maps in one solver (bb_solver_set_maps)
+    int n_maps = 1;
+    void *d_blk_scale = nullptr;         // T per block: the map's step
+    int *d_map_ptr = nullptr, *d_map_idx = nullptr;
+    double *d_map_scalar = nullptr;      // per-map stress of bb_solver_stress_maps
+    std::vector<int64_t> map_begin;      // first bin of every map, + n_bins
     int64_t *d_blk_ptr = nullptr, *d_blk_chunk = nullptr;    // final stage: one list per block
     int64_t *d_s1_ptr = nullptr, *d_s1_chunk = nullptr;      // stage 1: slices of long lists
     int64_t n_slices = 0, part2_off = 0;
@@ -247,7 +256,9 @@ int build_indices(bb_solver *s) {
     // itself, mid-sweep: rare); the strip a wave ENDS in shares one slot with the other
     // waves of its workgroup that end in the same strip (summed in LDS by the sweep's
     // epilogue).  BB_WG_COLSUM=0 gives every wave its own last slot too (for A/B).
-    std::vector<int32_t> slot_strip;
+    std::vector<int32_t> &slot_strip = s->slot_strip;
+    slot_strip.clear();
+    s->wave_last_strip.assign((size_t)nw, -1);
     std::vector<int2> wave_slots(nw);
     {
         const char *e = getenv("BB_WG_COLSUM");
@@ -263,6 +274,7 @@ int build_indices(bb_solver *s) {
             }
             for (size_t q = 0; q + 1 < strips.size(); ++q) slot_strip.push_back(strips[q]);
             const int Jlast = strips.back();
+            s->wave_last_strip[(size_t)w] = Jlast;
             const bool same_wg = w % s->wpb != 0;
             if (share && same_wg && wave_slots[w - 1].y >= 0 &&
                 slot_strip[(size_t)wave_slots[w - 1].y] == Jlast) {
@@ -374,6 +386,7 @@ int build_indices(bb_solver *s) {
         add(&s->d_wave_slots, nw);
         // nw partials (+ 8 stamps per wave, + one stamp per unit: diagnostic builds)
         add(&s->d_stresspart, nw * (9 + (abl::kUnitTrace ? abl::kUnitTraceSlots : 0)));
+        add(&s->d_stress_slot, std::max<int64_t>(s->n_slots, 1));
         add(&s->d_blk_ptr, nb + 1);
         add(&s->d_blk_chunk, (int64_t)fin_chunk.size());
         add(&s->d_s1_ptr, (int64_t)s1_ptr.size());
@@ -422,6 +435,9 @@ int build_indices(bb_solver *s) {
         BB_HIP_CHECK(hipMemsetAsync(s->d_X2, 0, (size_t)(s->L.n_pad * 3 * es), st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_exch, 0, (size_t)((3 * s->L.n_pad + 2) * es), st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_stresspart, 0, (size_t)nw * sizeof(double), st));
+    // (shared slots -- the strip a wave ENDS in -- carry no stress of their own: they stay 0)
+    BB_HIP_CHECK(hipMemsetAsync(s->d_stress_slot, 0,
+                                (size_t)std::max<int64_t>(s->n_slots, 1) * sizeof(double), st));
     BB_HIP_CHECK(hipStreamSynchronize(st));  // the host vectors above die with this scope
     return BB_OK;
 }
@@ -457,7 +473,7 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
         BB_HIP_CHECK(bb::launch(kern, grid, block, (size_t)(LDS), s->stream, units, X,          \
                                 s->d_udesc, s->chunk_q, s->chunk_r, s->d_wave_slots, rowpart,   \
                                 colpart, s->d_stresspart, s->defer_cap_units,                   \
-                                s->lds_wave_floats, s->wg_map, s->dense_u0));                   \
+                                s->lds_wave_floats, s->wg_map, s->dense_u0, s->d_stress_slot)); \
     } while (0)
 #define BB_LAUNCH2(NTV, OPV, DEF, LDS)                                                          \
     do {                                                                                        \
@@ -540,6 +556,12 @@ void fill_reduce_params(bb_solver *s, ReduceParams<T> &p, int mode, double lr, d
     p.blk_ptr = nullptr;
     p.blk_chunk = nullptr;
     p.mode = mode;
+    p.stress_slot = s->d_stress_slot;
+    p.n_slots = s->n_slots;
+    p.blk_scale = (const T *)s->d_blk_scale;
+    p.map_ptr = s->d_map_ptr;
+    p.map_idx = s->d_map_idx;
+    p.n_maps = s->n_maps;
 }
 
 template <typename T, bool W>
@@ -549,7 +571,8 @@ int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, doubl
     const unsigned segs = 3 * Lay<T, W>::VW / kRedWG;   // workgroups per block of 3*vw elements
     if (s->red_slices > 0) {
         // one launch: every list whole, 128 elements x 4 or 8 slices per workgroup
-        const dim3 grid = mode == kReduceStressOnly ? dim3(1, 1) : dim3((unsigned)s->L.n_blocks, segs);
+        const dim3 grid = mode == kReduceStressOnly ? dim3((unsigned)s->n_maps, 1)
+                                                    : dim3((unsigned)s->L.n_blocks, segs);
         if (s->red_slices == 4)
             BB_HIP_CHECK(bb::launch(reduce_sliced_kernel<T, W, 4>, grid, dim3(128 * 4), 0, s->stream,
                                     p, (const int64_t *)s->d_red_lists, s->red_stride));
@@ -568,7 +591,8 @@ int launch_reduce_t(bb_solver *s, int mode, double lr, double *stress_out, doubl
     p.blk_ptr = s->d_blk_ptr;
     p.blk_chunk = s->d_blk_chunk;
     p.mode = mode;
-    const dim3 grid = mode == kReduceStressOnly ? dim3(1, 1) : dim3((unsigned)s->L.n_blocks, segs);
+    const dim3 grid = mode == kReduceStressOnly ? dim3((unsigned)s->n_maps, 1)
+                                                : dim3((unsigned)s->L.n_blocks, segs);
     BB_HIP_CHECK(bb::launch(reduce_kernel<T, W>, grid, dim3(kRedWG), 0, s->stream, p));
     return BB_OK;
 }
@@ -619,10 +643,13 @@ hipError_t narrow(bb_solver *s, const double *in_f64, void *out_T, int64_t n) {
                             (double *)out_T, n);
 }
 
+// host = the (n_sub, n_sub) matrix of the bins [off, off + n_sub) of the solver (the whole
+// map: off = 0, n_sub = n_bins); only units inside that block are touched
 template <typename T, bool W>
-int set_wish_dense_t(bb_solver *s, const double *host, int64_t ld, int kind, double alpha) {
+int set_wish_dense_t(bb_solver *s, const double *host, int64_t ld, int kind, double alpha,
+                     int64_t off, int64_t n_sub) {
     constexpr int VW = Lay<T, W>::VW;
-    const int64_t upt = s->L.units_per_tile, n = s->L.n_bins;
+    const int64_t upt = s->L.units_per_tile, n = off + n_sub;
     constexpr int64_t kRunTiles = 4;  // tiles staged per copy
     double *stage = nullptr;
     BB_TRY(dev_alloc(&stage, kRunTiles * VW * VW));
@@ -634,6 +661,7 @@ int set_wish_dense_t(bb_solver *s, const double *host, int64_t ld, int kind, dou
         // a run: consecutive local units whose rows are consecutive in one strip
         const int j0 = s->udesc[ul].y;
         const int64_t i_start = s->udesc[ul].x;
+        if (j0 < off || j0 >= n || i_start < off) { ++ul; continue; }      // another map's unit
         int64_t ue = ul + 1;
         while (ue < s->n_local && ue - ul < kRunTiles * upt && s->udesc[ue].y == j0 &&
                s->udesc[ue].x == i_start + (ue - ul) * s->L.rows_per_unit)
@@ -647,7 +675,7 @@ int set_wish_dense_t(bb_solver *s, const double *host, int64_t ld, int kind, dou
         if (rows_valid < rows || cols_valid < VW)
             e = hipMemsetAsync(stage, 0, (size_t)rows * VW * sizeof(double), s->stream);
         if (e == hipSuccess && rows_valid > 0 && cols_valid > 0)
-            e = hipMemcpy2DAsync(stage, VW * sizeof(double), host + i_start * ld + j0,
+            e = hipMemcpy2DAsync(stage, VW * sizeof(double), host + (i_start - off) * ld + (j0 - off),
                                  (size_t)ld * sizeof(double), (size_t)cols_valid * sizeof(double),
                                  (size_t)rows_valid, hipMemcpyHostToDevice, s->stream);
         if (e == hipSuccess) {
@@ -873,6 +901,10 @@ int bb_solver_destroy(bb_solver *s) {
     hipFree(s->d_peer_counter);
     for (hipEvent_t e : s->ev) hipEventDestroy(e);
     hipFree(s->d_arena);
+    hipFree(s->d_blk_scale);
+    hipFree(s->d_map_ptr);
+    hipFree(s->d_map_idx);
+    hipFree(s->d_map_scalar);
     if (s->own_exch) hipFree(s->d_exch);
     hipFree(s->d_mv_in);
     // (a stream abandoned behind a hung collective is not returned to the pool: the pool
@@ -911,14 +943,128 @@ int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld, int k
                "bb_solver_set_wish_dense: bad kind");
     BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_dense: alpha must be > 0");
     BB_TRY(bb::enter_device(s->device));
-    int rc = BB_BY_LAYOUT(s, set_wish_dense_t, s, host, ld, kind, alpha);
+    int rc = BB_BY_LAYOUT(s, set_wish_dense_t, s, host, ld, kind, alpha, (int64_t)0, s->L.n_bins);
     if (rc == BB_OK) rc = refresh_full(s);
     if (rc == BB_OK) s->have_wish = true;
     return rc;
 }
 
+int bb_solver_set_maps(bb_solver *s, int n_maps, const int64_t *bin_begin, const double *lr_scale) {
+    BB_REQUIRE(s != nullptr && bin_begin != nullptr && lr_scale != nullptr,
+               "bb_solver_set_maps: NULL argument");
+    BB_REQUIRE(n_maps >= 1 && n_maps <= s->L.n_blocks, "bb_solver_set_maps: bad n_maps");
+    if (s->world != 1)
+        return bb::fail(BB_ERR_STATE, "bb_solver_set_maps: one rank only (on several GPUs give every "
+                                      "rank maps of its own)");
+    const int64_t vw = s->L.vw, nb = s->L.n_blocks;
+    BB_REQUIRE(bin_begin[0] == 0 && bin_begin[n_maps] == s->L.n_bins,
+               "bb_solver_set_maps: bin_begin must run from 0 to n_bins");
+    for (int m = 0; m < n_maps; ++m)
+        BB_REQUIRE(bin_begin[m] % vw == 0 && bin_begin[m + 1] > bin_begin[m],
+                   "bb_solver_set_maps: every map starts at a multiple of the tile edge and is not empty");
+    BB_TRY(bb::enter_device(s->device));
+    std::vector<int> map_of_block((size_t)nb, 0);
+    for (int m = 0, b = 0; b < nb; ++b) {
+        while (m + 1 < n_maps && (int64_t)b * vw >= bin_begin[m + 1]) ++m;
+        map_of_block[(size_t)b] = m;
+    }
+    for (size_t t = 0; t < s->tile_I.size(); ++t)
+        BB_REQUIRE(map_of_block[(size_t)s->tile_I[t]] == map_of_block[(size_t)s->tile_J[t]],
+                   "bb_solver_set_maps: a tile of the solver's list joins two maps");
+    // per block: the map's step; per map: its stress partials (wave w's own, index w, belongs
+    // to the strip the wave ends in; slot q's, index n_waves + q, to the slot's strip)
+    const int64_t es = bb::elem_size(s->dtype);
+    std::vector<char> scale((size_t)(nb * es));
+    for (int64_t b = 0; b < nb; ++b) {
+        const double v = lr_scale[map_of_block[(size_t)b]];
+        if (s->dtype == BB_F32) ((float *)scale.data())[b] = (float)v;
+        else ((double *)scale.data())[b] = v;
+    }
+    std::vector<std::vector<int>> lists((size_t)n_maps);
+    for (int w = 0; w < s->n_waves; ++w)
+        if (s->wave_last_strip[(size_t)w] >= 0)
+            lists[(size_t)map_of_block[(size_t)s->wave_last_strip[(size_t)w]]].push_back(w);
+    for (int q = 0; q < s->n_slots; ++q)
+        lists[(size_t)map_of_block[(size_t)s->slot_strip[(size_t)q]]].push_back(s->n_waves + q);
+    std::vector<int> ptr(1, 0), idx;
+    for (auto &l : lists) {
+        idx.insert(idx.end(), l.begin(), l.end());
+        ptr.push_back((int)idx.size());
+    }
+    if (idx.empty()) idx.push_back(0);
+    hipFree(s->d_blk_scale); hipFree(s->d_map_ptr); hipFree(s->d_map_idx); hipFree(s->d_map_scalar);
+    s->d_blk_scale = nullptr; s->d_map_ptr = s->d_map_idx = nullptr; s->d_map_scalar = nullptr;
+    BB_TRY(dev_alloc((char **)&s->d_blk_scale, nb * es));
+    BB_TRY(dev_alloc(&s->d_map_ptr, (int64_t)ptr.size()));
+    BB_TRY(dev_alloc(&s->d_map_idx, (int64_t)idx.size()));
+    BB_TRY(dev_alloc(&s->d_map_scalar, n_maps));
+    BB_HIP_CHECK(hipMemcpy(s->d_blk_scale, scale.data(), scale.size(), hipMemcpyHostToDevice));
+    BB_HIP_CHECK(hipMemcpy(s->d_map_ptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    BB_HIP_CHECK(hipMemcpy(s->d_map_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    // (a map that is never set carries no constraint)
+    BB_HIP_CHECK(hipMemsetAsync(s->d_units, 0, (size_t)std::max<int64_t>(s->n_local, 1) * bb::kUnitBytes,
+                                s->stream));
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    s->n_maps = n_maps;
+    s->map_begin.assign(bin_begin, bin_begin + n_maps + 1);
+    s->row_owner = false;          // the sweep: its reduce knows the maps
+    s->hist_n = 0;
+    return BB_OK;
+}
+
+int bb_solver_set_wish_from_cm_block(bb_solver *s, const bb_cm *cm, int64_t bin_offset, int kind,
+                                     double alpha) {
+    BB_REQUIRE(s != nullptr && cm != nullptr, "bb_solver_set_wish_from_cm_block: NULL argument");
+    BB_REQUIRE(kind == BB_KIND_WISH || kind == BB_KIND_COUNTS,
+               "bb_solver_set_wish_from_cm_block: bad kind");
+    BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_from_cm_block: alpha must be > 0");
+    const double *m = nullptr;
+    int64_t d = 0;
+    int dev = -1;
+    BB_TRY(bb_cm_device_ptr(cm, &m, &d, &dev));
+    BB_REQUIRE(d >= 1 && bin_offset >= 0 && bin_offset % s->L.vw == 0 && bin_offset + d <= s->L.n_bins,
+               "bb_solver_set_wish_from_cm_block: the map does not fit the solver at that offset");
+    BB_REQUIRE(dev == s->device,
+               "bb_solver_set_wish_from_cm_block: the map lives on another device than the solver");
+    BB_TRY(bb::enter_device(s->device));
+    if (s->n_local > 0) {
+#define BB_PACKB(TT, WW)                                                                         \
+    BB_HIP_CHECK(bb::launch(pack_units_from_matrix_kernel<TT, WW>, dim3((unsigned)s->n_local),       \
+                            dim3(256), 0, s->stream, m, d, (TT *)s->d_units, s->d_udesc,          \
+                            bin_offset + d, kind, -1.0 / alpha, bin_offset))
+        if (s->dtype == BB_F32) BB_PACKB(float, true);
+        else if (s->wide) BB_PACKB(double, true);
+        else BB_PACKB(double, false);
+#undef BB_PACKB
+    }
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    s->have_wish = true;
+    return BB_OK;
+}
+
+int bb_solver_set_wish_dense_block(bb_solver *s, const double *host, int64_t ld, int64_t n_sub,
+                                   int64_t bin_offset, int kind, double alpha) {
+    BB_REQUIRE(s != nullptr && host != nullptr, "bb_solver_set_wish_dense_block: NULL argument");
+    BB_REQUIRE(n_sub >= 1 && bin_offset >= 0 && bin_offset + n_sub <= s->L.n_bins && ld >= n_sub,
+               "bb_solver_set_wish_dense_block: the block does not fit the solver");
+    BB_REQUIRE(bin_offset % s->L.vw == 0,
+               "bb_solver_set_wish_dense_block: a block starts at a multiple of the tile edge");
+    BB_REQUIRE(kind == BB_KIND_WISH || kind == BB_KIND_COUNTS,
+               "bb_solver_set_wish_dense_block: bad kind");
+    BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_dense_block: alpha must be > 0");
+    BB_TRY(bb::enter_device(s->device));
+    int rc = BB_BY_LAYOUT(s, set_wish_dense_t, s, host, ld, kind, alpha, bin_offset, n_sub);
+    if (rc == BB_OK) s->have_wish = true;
+    return rc;
+}
+
+int bb_solver_set_wish_from_cm_block(bb_solver *s, const bb_cm *cm, int64_t bin_offset, int kind,
+                                     double alpha);
 int bb_solver_set_wish_from_cm(bb_solver *s, const bb_cm *cm, int kind, double alpha) {
     BB_REQUIRE(s != nullptr && cm != nullptr, "bb_solver_set_wish_from_cm: NULL argument");
+    if (s->n_maps > 1)
+        return bb::fail(BB_ERR_STATE, "bb_solver_set_wish_from_cm: a solver of several maps takes "
+                                      "them one by one (bb_solver_set_wish_from_cm_block)");
     BB_REQUIRE(kind == BB_KIND_WISH || kind == BB_KIND_COUNTS,
                "bb_solver_set_wish_from_cm: bad kind");
     BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_from_cm: alpha must be > 0");
@@ -935,7 +1081,7 @@ int bb_solver_set_wish_from_cm(bb_solver *s, const bb_cm *cm, int kind, double a
 #define BB_PACK(TT, WW)                                                                          \
     BB_HIP_CHECK(bb::launch(pack_units_from_matrix_kernel<TT, WW>, dim3((unsigned)s->n_local),       \
                             dim3(256), 0, s->stream, m, d, (TT *)s->d_units, s->d_udesc,          \
-                            s->L.n_bins, kind, -1.0 / alpha))
+                            s->L.n_bins, kind, -1.0 / alpha, (int64_t)0))
         if (s->dtype == BB_F32) BB_PACK(float, true);
         else if (s->wide) BB_PACK(double, true);
         else BB_PACK(double, false);
@@ -1234,7 +1380,7 @@ int bb_solver_iterate(bb_solver *s, int64_t iters, double lr) {
         return bb::fail(BB_ERR_STATE,
                         "bb_solver_iterate: world > 1 needs bb_solver_grad / all-reduce / "
                         "bb_solver_apply");
-    if (s->hist_n + iters > s->hist_cap)
+    if ((s->hist_n + iters) * s->n_maps > s->hist_cap)
         return bb::fail(BB_ERR_STATE, "bb_solver_iterate: stress history full");
     BB_TRY(bb::enter_device(s->device));
     if (s->row_owner) {
@@ -1255,7 +1401,7 @@ int bb_solver_iterate(bb_solver *s, int64_t iters, double lr) {
         if (ev) BB_HIP_CHECK(hipEventRecord(ev[0], s->stream));
         BB_TRY(launch_grad(s));
         if (ev) BB_HIP_CHECK(hipEventRecord(ev[1], s->stream));
-        BB_TRY(launch_reduce(s, kReduceApply, lr, s->d_stress_hist + s->hist_n));
+        BB_TRY(launch_reduce(s, kReduceApply, lr, s->d_stress_hist + s->hist_n * s->n_maps));
         if (ev) BB_HIP_CHECK(hipEventRecord(ev[2], s->stream));
         s->hist_n++;
     }
@@ -1264,6 +1410,9 @@ int bb_solver_iterate(bb_solver *s, int64_t iters, double lr) {
 
 int bb_solver_grad(bb_solver *s) {
     BB_TRY(check_ready(s, "bb_solver_grad"));
+    if (s->n_maps > 1)
+        return bb::fail(BB_ERR_STATE, "bb_solver_grad: a solver of several maps (bb_solver_set_maps) "
+                                      "iterates with bb_solver_iterate only");
     BB_TRY(bb::enter_device(s->device));
     hipEvent_t *ev = timing_slot(s);
     if (ev) BB_HIP_CHECK(hipEventRecord(ev[0], s->stream));
@@ -1837,6 +1986,8 @@ int bb_solver_write_exchange(bb_solver *s, const double *host, int64_t n) {
 int bb_solver_matvec_sq(bb_solver *s, const double *x, double *y) {
     BB_REQUIRE(s != nullptr && x != nullptr && y != nullptr, "bb_solver_matvec_sq: NULL argument");
     if (!s->have_wish) return bb::fail(BB_ERR_STATE, "bb_solver_matvec_sq: no wish distances set");
+    if (s->n_maps > 1)
+        return bb::fail(BB_ERR_STATE, "bb_solver_matvec_sq: not for a solver of several maps");
     if (s->grad_pending)
         return bb::fail(BB_ERR_STATE, "bb_solver_matvec_sq: a bb_solver_grad is pending");
     BB_TRY(bb::enter_device(s->device));
@@ -1871,9 +2022,31 @@ int bb_solver_stress(bb_solver *s, double *stress) {
     BB_REQUIRE(stress != nullptr, "bb_solver_stress: stress is NULL");
     BB_TRY(bb::enter_device(s->device));
     BB_TRY(launch_grad(s));
+    if (s->n_maps > 1) {                       // the sum over the maps
+        std::vector<double> per((size_t)s->n_maps);
+        BB_TRY(launch_reduce(s, kReduceStressOnly, 0.0, s->d_map_scalar));
+        BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+        BB_HIP_CHECK(hipMemcpy(per.data(), s->d_map_scalar, per.size() * sizeof(double),
+                               hipMemcpyDeviceToHost));
+        *stress = 0.0;
+        for (double v : per) *stress += v;
+        return BB_OK;
+    }
     BB_TRY(launch_reduce(s, kReduceStressOnly, 0.0, s->d_stress_scalar));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
     BB_HIP_CHECK(hipMemcpy(stress, s->d_stress_scalar, sizeof(double), hipMemcpyDeviceToHost));
+    return BB_OK;
+}
+
+int bb_solver_stress_maps(bb_solver *s, double *stress, int n_maps) {
+    BB_TRY(check_ready(s, "bb_solver_stress_maps"));
+    BB_REQUIRE(stress != nullptr && n_maps == s->n_maps, "bb_solver_stress_maps: bad argument");
+    BB_TRY(bb::enter_device(s->device));
+    BB_TRY(launch_grad(s));
+    double *out = s->n_maps > 1 ? s->d_map_scalar : s->d_stress_scalar;
+    BB_TRY(launch_reduce(s, kReduceStressOnly, 0.0, out));
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    BB_HIP_CHECK(hipMemcpy(stress, out, (size_t)s->n_maps * sizeof(double), hipMemcpyDeviceToHost));
     return BB_OK;
 }
 
@@ -1881,8 +2054,9 @@ int bb_solver_get_stress_history(bb_solver *s, double *out, int64_t cap, int64_t
     BB_REQUIRE(s != nullptr && n != nullptr, "bb_solver_get_stress_history: NULL argument");
     BB_TRY(bb::enter_device(s->device));
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
-    *n = s->hist_n;
-    const int64_t m = std::min(cap, s->hist_n);
+    // (several maps: iteration-major, n_maps values per iteration)
+    *n = s->hist_n * s->n_maps;
+    const int64_t m = std::min(cap, s->hist_n * s->n_maps);
     if (out && m > 0)
         BB_HIP_CHECK(hipMemcpy(out, s->d_stress_hist, (size_t)m * sizeof(double),
                                hipMemcpyDeviceToHost));
@@ -2285,6 +2459,9 @@ extern "C" int bb_solver_spectral_init(bb_solver *s, int n_iter, const double *v
                                       "over the ranks");
     if (s->grad_pending)
         return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: a bb_solver_grad is pending");
+    if (s->n_maps > 1)
+        return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: not for a solver of several maps "
+                                      "(start each map with a solver of its own)");
     BB_REQUIRE(s->L.n_bins >= 3, "bb_solver_spectral_init: needs at least 3 bins");
     BB_TRY(bb::enter_device(s->device));
     const int rc = s->dtype == BB_F32 ? spectral_init_t<float>(s, n_iter, v0)

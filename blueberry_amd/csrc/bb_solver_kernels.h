@@ -744,7 +744,8 @@ __device__ __forceinline__ void wave_stamp(double *stresspart, int n_waves, int 
 //              the strip the wave ENDS in (-1: the wave has no units)}; see the epilogue
 //   rowpart    3*RPU elements per unit, base shifted to the rank's first tile
 //   colpart    3*VW elements per slot
-//   stresspart one double per wave
+//   stresspart one double per wave: the stress of the strip the wave ENDS in
+//   stress_slot one double per private column slot: the stress of a strip the wave left
 //
 // DEFER (fp32 only): the row sums do not leave the wave unit by unit.  Writing 48
 // bytes to a fresh line per 8 KiB read costs 7.5 % of the kernel at N=50k, and not in
@@ -772,7 +773,7 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
     const T *__restrict__ units, const T *__restrict__ X, const int2 *__restrict__ udesc,
     int chunk_q, int chunk_r, const int2 *__restrict__ wave_slots, T *__restrict__ rowpart,
     T *__restrict__ colpart, double *__restrict__ stresspart, int cap_units, int lds_wave_floats,
-    int wg_map, int dense_u0) {
+    int wg_map, int dense_u0, double *__restrict__ stress_slot) {
     using Vec = typename Traits<T>::Vec;
     constexpr int VPL = Traits<T>::VPL;
     constexpr int VW = Lay<T, W>::VW;
@@ -1076,6 +1077,14 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
             }
             if (u >= ub) break;      // the wave's last strip: its column partial goes out below
             strip_store(slot);
+            // the stress of the strip left behind goes with its slot (rare: once per strip a
+            // wave crosses), so that every stress partial belongs to ONE strip -- and with
+            // several maps in one solver (bb_solver_set_maps) to one map
+            {
+                const double sv = wave_sum_hi(stress);
+                if (lane == 63) stress_slot[slot] = sv;
+                stress = 0.0;
+            }
             ++slot;
         }
         if constexpr (WPB == 8) {
@@ -1230,7 +1239,33 @@ struct ReduceParams {
     int n_waves;
     int mode;
     T lr;
+    const double *__restrict__ stress_slot;  // per private column slot (see the sweep)
+    int n_slots;
+    // several maps in one solver (bb_solver_set_maps; world = 1): the step of block b is
+    // lr * blk_scale[b], and the stress is folded per map -- map m's partials are
+    // map_idx[map_ptr[m] .. map_ptr[m + 1]) (index < n_waves: stresspart, else stress_slot) --
+    // into stress_out[m].  n_maps <= 1: one map, every partial, stress_out[0].
+    const T *__restrict__ blk_scale;
+    const int *__restrict__ map_ptr;
+    const int *__restrict__ map_idx;
+    int n_maps;
 };
+
+// this thread's share of map `m`'s stress partials (stride = threads of the workgroup)
+template <typename T>
+__device__ __forceinline__ double stress_share(const ReduceParams<T> &p, int m, int tid, int stride) {
+    double s = 0.0;
+    if (p.n_maps <= 1) {
+        for (int i = tid; i < p.n_waves; i += stride) s += p.stresspart[i];
+        for (int i = tid; i < p.n_slots; i += stride) s += p.stress_slot[i];
+    } else {
+        for (int i = p.map_ptr[m] + tid; i < p.map_ptr[m + 1]; i += stride) {
+            const int idx = p.map_idx[i];
+            s += idx < p.n_waves ? p.stresspart[idx] : p.stress_slot[idx - p.n_waves];
+        }
+    }
+    return s;
+}
 
 constexpr int kRedWG = 128;  // threads per reduce workgroup = elements it sums
 // Grid: x = the block (or stage-1 slice) of the list, y = which kRedWG of the block's
@@ -1273,7 +1308,8 @@ __global__ __launch_bounds__(kRedWG) void reduce_kernel(ReduceParams<T> p) {
             const T g = p.scale * acc;
             if (p.mode == kReduceApply) {
                 // SPEC 2.4: V <- mu V - lr g ; X <- X + V   (mu = 0: X -= lr g)
-                const T v = p.mu * p.V[o] - p.lr * g;
+                const T lr = p.blk_scale ? p.lr * p.blk_scale[b] : p.lr;
+                const T v = p.mu * p.V[o] - lr * g;
                 p.V[o] = v;
                 p.X[o] += v;
             } else if (p.mode == kReducePeer) {
@@ -1296,11 +1332,9 @@ __global__ __launch_bounds__(kRedWG) void reduce_kernel(ReduceParams<T> p) {
         }
     }
     if (p.mode == kReducePartial) return;
-    if (b == 0 && blockIdx.y == 0) {
+    if (b < (p.n_maps > 1 ? p.n_maps : 1) && blockIdx.y == 0) {
         __shared__ double sh[kRedWG];
-        double s = 0.0;
-        for (int i = tid; i < p.n_waves; i += kRedWG) s += p.stresspart[i];
-        sh[tid] = s;
+        sh[tid] = stress_share(p, b, tid, kRedWG);
         __syncthreads();
         for (int off = kRedWG / 2; off > 0; off >>= 1) {
             if (tid < off) sh[tid] += sh[tid + off];
@@ -1319,7 +1353,7 @@ __global__ __launch_bounds__(kRedWG) void reduce_kernel(ReduceParams<T> p) {
                     p.peer->dst[q][3 * p.n_pad + 1] = lo;
                 }
             } else {
-                *p.stress_out = S;
+                p.stress_out[b] = S;
             }
         }
     }
@@ -1392,7 +1426,8 @@ __global__ __launch_bounds__(128 * S) void reduce_sliced_kernel(ReduceParams<T> 
             const T g = p.scale * tot;
             if (p.mode == kReduceApply) {
                 // SPEC 2.4: V <- mu V - lr g ; X <- X + V   (mu = 0: X -= lr g)
-                const T v = p.mu * vo - p.lr * g;
+                const T lr = p.blk_scale ? p.lr * p.blk_scale[b] : p.lr;
+                const T v = p.mu * vo - lr * g;
                 p.V[o] = v;
                 p.X[o] = xo + v;
             } else if (p.mode == kReducePeer) {
@@ -1412,12 +1447,10 @@ __global__ __launch_bounds__(128 * S) void reduce_sliced_kernel(ReduceParams<T> 
             }
         }
     }
-    if (b == 0 && blockIdx.y == 0) {
-        // the stress: per-wave partials of the sweep, fixed tree
+    if (b < (p.n_maps > 1 ? p.n_maps : 1) && blockIdx.y == 0) {
+        // the stress: per-wave and per-slot partials of the sweep, fixed tree
         __shared__ double sh[128 * S];
-        double s = 0.0;
-        for (int i = tid; i < p.n_waves; i += 128 * S) s += p.stresspart[i];
-        sh[tid] = s;
+        sh[tid] = stress_share(p, b, tid, 128 * S);
         __syncthreads();
         for (int off = 64 * S; off > 0; off >>= 1) {
             if (tid < off) sh[tid] += sh[tid + off];
@@ -1436,7 +1469,7 @@ __global__ __launch_bounds__(128 * S) void reduce_sliced_kernel(ReduceParams<T> 
                     p.peer->dst[q][3 * p.n_pad + 1] = lo;
                 }
             } else {
-                *p.stress_out = Sx;
+                p.stress_out[b] = Sx;
             }
         }
     }
@@ -1623,11 +1656,8 @@ __global__ __launch_bounds__(128 * S) void reduce_exchange_kernel(
     }
     meet[sl][el] = acc;
     const bool first = b == 0 && blockIdx.y == 0;
-    if (first) {
-        double s = 0.0;                       // the stress: per-wave partials of the sweep, fixed tree
-        for (int i = tid; i < p.n_waves; i += 128 * S) s += p.stresspart[i];
-        sh[tid] = s;
-    }
+    if (first)                                // the stress: the sweep's partials, fixed tree
+        sh[tid] = stress_share(p, 0, tid, 128 * S);
     if (__syncthreads_or(dead_here) != 0) return;
     if (first) {
         for (int off = 64 * S; off > 0; off >>= 1) {
@@ -1851,17 +1881,20 @@ __global__ __launch_bounds__(256) void convert_units_kernel(
 template <typename T, bool W>
 __global__ __launch_bounds__(256) void pack_units_from_matrix_kernel(
     const double *__restrict__ m, int64_t ld, T *__restrict__ units_out,
-    const int2 *__restrict__ udesc, int64_t n_bins, int kind, double neg_inv_alpha) {
+    const int2 *__restrict__ udesc, int64_t n_bins, int kind, double neg_inv_alpha, int64_t off) {
+    // (off > 0: m is the matrix of the bins [off, n_bins) of a solver of several maps; units of
+    // other maps are left alone)
     constexpr int VW = Lay<T, W>::VW, RPU = Lay<T, W>::RPU;
     const int64_t ul = blockIdx.x;
     const int2 dsc = udesc[ul];
+    if (dsc.y < off || dsc.y >= n_bins || dsc.x < off) return;
     T *out = units_out + ul * (RPU * VW);
     for (int e = threadIdx.x; e < RPU * VW; e += 256) {
         const int r = e / VW, c = e % VW;
         const int64_t i = (int64_t)dsc.x + r, j = (int64_t)dsc.y + c;
         double v = 0.0;
         if (j > i && j < n_bins) {
-            v = m[i * ld + j];
+            v = m[(i - off) * ld + (j - off)];
             const bool ok = (v > 0.0) && (v <= 1.7976931348623157e308);  // finite, positive
             if (!ok)
                 v = 0.0;

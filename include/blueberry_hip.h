@@ -127,6 +127,27 @@ BB_API int bb_solver_layout(const bb_solver *s, bb_layout_info *info, int64_t *u
  * Each rank uploads only its own units. */
 BB_API int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld, int kind,
                                     double alpha);
+/* SEVERAL MAPS IN ONE SOLVER.  The reference's ContactMap is per chromosome
+ * (blueberry/datatypes.pyx:88), so the common job is 23 maps of 1,000-5,000 bins, each of
+ * which alone is launch-bound (5-20 us per iteration whatever its size).  Laid end to end --
+ * map m owns the bins [bin_begin[m], bin_begin[m+1]), every map starting at a multiple of the
+ * tile edge, the solver created with the tile list of the maps' own dense triangles (no tile
+ * joins two maps) -- they are ONE blocked-sparse problem: one sweep and one reduce per
+ * iteration for all of them.
+ *   bb_solver_set_maps            declare the maps (world = 1); map m steps with
+ *                                 lr * lr_scale[m] (bb_solver_iterate's lr times it: pass
+ *                                 lr = 1 and lr_scale[m] = 1 / (2 n_m) for the SMACOF step),
+ *                                 and the stress is kept PER MAP: bb_solver_get_stress_history
+ *                                 then returns n_maps values per iteration (iteration-major)
+ *   bb_solver_set_wish_dense_block  map m's (n_sub, n_sub) host matrix into its bins
+ *                                 [bin_offset, bin_offset + n_sub); as bb_solver_set_wish_dense
+ *   bb_solver_stress_maps         per-map stress of the current coordinates
+ * Coordinates travel as one (n_bins, 3) array (rows between the maps are padding: 0). */
+BB_API int bb_solver_set_maps(bb_solver *s, int n_maps, const int64_t *bin_begin,
+                              const double *lr_scale);
+BB_API int bb_solver_set_wish_dense_block(bb_solver *s, const double *host, int64_t ld,
+                                          int64_t n_sub, int64_t bin_offset, int kind, double alpha);
+BB_API int bb_solver_stress_maps(bb_solver *s, double *stress, int n_maps);
 /* Blocked-sparse input: nnz entries (rows[k], cols[k], vals[k]) of the symmetric
  * matrix, either triangle; an unordered pair that occurs more than once keeps its
  * LAST entry, as in the reference's scatter loop (blueberry/datatypes.pyx:110-116)
@@ -422,6 +443,10 @@ BB_API int bb_cm_release_scratch(int device);
 /* Hand the resident matrix to a solver of n_bins = d bins on the same device, device
  * to device (same meaning of kind / alpha as bb_solver_set_wish_dense). */
 BB_API int bb_solver_set_wish_from_cm(bb_solver *s, const bb_cm *cm, int kind, double alpha);
+/* The same into the bins [bin_offset, bin_offset + d) of a solver of several maps
+ * (bb_solver_set_maps), d = the map's edge. */
+BB_API int bb_solver_set_wish_from_cm_block(bb_solver *s, const bb_cm *cm, int64_t bin_offset,
+                                            int kind, double alpha);
 
 /* The same two loops around a HOST matrix (round-1 entry points; upload, kernel,
  * download): */

@@ -1258,6 +1258,110 @@ def test_genome10kb_workload_full_size_vs_oracle_and_properties(oracle):
     assert abs((acc[-2] + acc[-1]) / (full[-2] + full[-1]) - 1) < 1e-6
 
 
+# ---- several maps in one solver (fit_many) -------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-12), ("float32", 1e-5)])
+@pytest.mark.parametrize("mu", [0.0, 0.4])
+def test_fit_many_equals_the_oracle_map_by_map(oracle, dtype, tol, mu):
+    """per-chromosome maps batched into ONE solver (bb_solver_set_maps: one
+    sweep + one reduce launch per iteration for all of them, a step and a stress history
+    per map).  Every map against the oracle's own K-step solve of that map alone, and
+    against its single fit() -- at the solver's tolerance (the partial sums are cut
+    differently, so not bit for bit).  Sizes straddle tile edges; one map is resident."""
+    sizes, k = [700, 1300, 2049, 963, 512], 6
+    mats, x0s = [], []
+    for q, n in enumerate(sizes):
+        xs = _oracle.random_walk(n, seed=10 + q)
+        w = _oracle.wish_from_coords(xs)
+        if q == 1:
+            w[5, 900] = w[900, 5] = 0.0                     # a missing pair
+        mats.append(w)
+        x0s.append(_oracle.noisy_init(xs, seed=20 + q))
+    inputs = list(mats)
+    inputs[3] = bb.ContactMap.from_matrix(mats[3])
+    inputs[3]._resident()                                    # packed device to device
+    s = bb.StructureSolver(n_iter=k, dtype=dtype, kind="wish", momentum=mu).fit_many(inputs, inits=x0s)
+    assert s.n_bins_many_ == sizes and s.n_iter_ == k
+    for q, n in enumerate(sizes):
+        lr = 1.0 / (2 * n)
+        X_ref, h_ref = (oracle.solve_momentum(mats[q], x0s[q], k, lr, mu, f64=dtype == "float64")
+                        if mu else oracle.solve(mats[q], x0s[q], k, lr, f64=dtype == "float64"))
+        assert s.lrs_[q] == lr and s.structures_[q].shape == (n, 3)
+        assert numpy.abs(s.stresses_[q] / h_ref - 1).max() < tol, (q, dtype)
+        assert _rel(s.structures_[q], X_ref) < tol, (q, dtype)
+        one = bb.StructureSolver(n_iter=k, dtype=dtype, kind="wish", momentum=mu).fit(mats[q], init=x0s[q])
+        assert numpy.abs(s.stresses_[q] / one.stress_ - 1).max() < tol
+        assert _rel(s.structures_[q], one.structure_) < tol
+
+
+def test_fit_many_defaults_early_stop_and_spectral():
+    sizes = [600, 1500, 900]
+    mats = [_oracle.wish_from_coords(_oracle.random_walk(n, seed=30 + q)) for q, n in enumerate(sizes)]
+    # default starts: the seeded normal of fit(), map by map
+    a = bb.StructureSolver(n_iter=5, dtype="float64", kind="wish", seed=4).fit_many(mats)
+    for q, m in enumerate(mats):
+        one = bb.StructureSolver(n_iter=5, dtype="float64", kind="wish", seed=4).fit(m)
+        assert _rel(a.structures_[q], one.structure_) < 1e-12
+        assert (numpy.diff(a.stresses_[q]) < 0).all()
+    # early stop: every map has to have converged
+    near = [_oracle.noisy_init(_oracle.random_walk(n, seed=30 + q), seed=7) for q, n in enumerate(sizes)]
+    b = bb.StructureSolver(n_iter=400, dtype="float64", kind="wish", tol=1e-2,
+                           check_every=5).fit_many(mats, inits=near)
+    assert 5 <= b.n_iter_ < 400 and b.n_iter_ % 5 == 0
+    for h in b.stresses_:
+        assert abs(h[-2] - h[-1]) <= 1e-2 * h[-2]
+    early = bb.StructureSolver(n_iter=b.n_iter_ - 5, dtype="float64", kind="wish").fit_many(mats, inits=near)
+    assert any(abs(h[-2] - h[-1]) > 1e-2 * h[-2] for h in early.stresses_)   # it stopped when ALL had
+    # spectral: each map starts from its own classical-MDS solution (complete maps: exact)
+    c = bb.StructureSolver(n_iter=2, dtype="float64", kind="wish", init="spectral").fit_many(mats)
+    for q, m in enumerate(mats):
+        assert c.stresses_[q][0] < 1e-8 * a.stresses_[q][0]
+        assert numpy.abs(_oracle.wish_from_coords(c.structures_[q]) - m).max() < 1e-5 * m.max()
+    with pytest.raises(ValueError):
+        bb.StructureSolver().fit_many([])
+    with pytest.raises(ValueError):
+        bb.StructureSolver().fit_many([numpy.zeros((3, 4))])
+
+
+def test_several_maps_engine_level_properties():
+    """The C-ABI directly: per-map stress (bb_solver_stress_maps) adds up to bb_solver_stress,
+    a tile that joins two maps is refused, multi-rank solvers refuse maps, and the padding rows
+    between the maps never move."""
+    sizes = [700, 600]
+    off = [0, 1024]
+    total = off[1] + sizes[1]
+    tiles = (numpy.array([0, 0, 1, 2], dtype=numpy.int32), numpy.array([0, 1, 1, 2], dtype=numpy.int32))
+    e = HipEngine(total, "float32", tiles=tiles)
+    e.set_maps(off + [total], [1.0 / 1400, 1.0 / 1200])
+    ws = [_oracle.wish_from_coords(_oracle.random_walk(n, seed=q)) for q, n in enumerate(sizes)]
+    for o, w in zip(off, ws):
+        e.set_wish_dense_block(w, o, "wish", 3.0)
+    x0 = numpy.zeros((total, 3))
+    for q, (o, n) in enumerate(zip(off, sizes)):
+        x0[o:o + n] = _oracle.noisy_init(_oracle.random_walk(n, seed=q), seed=5 + q)
+    e.set_coords(x0)
+    per = e.stress_maps()
+    assert per.shape == (2,) and abs(per.sum() / e.stress() - 1) < 1e-12
+    for q, (o, n) in enumerate(zip(off, sizes)):
+        s_q, _ = _oracle.load().stress_grad(ws[q], x0[o:o + n], f64=False)
+        assert abs(per[q] / s_q - 1) < 1e-5
+    e.iterate(3, 1.0)
+    X = e.get_coords()
+    assert not X[700:1024].any()                               # padding between the maps
+    assert e.stress_history().shape == (6,)                    # 3 iterations x 2 maps
+    with pytest.raises(RuntimeError):
+        e.grad()
+    e.close()
+    bad = (numpy.array([0, 0, 1], dtype=numpy.int32), numpy.array([0, 1, 1], dtype=numpy.int32))
+    e = HipEngine(1024, "float32", tiles=bad)
+    with pytest.raises(ValueError, match="joins two maps"):
+        e.set_maps([0, 512, 1024], [1.0, 1.0])
+    e.close()
+    e = HipEngine(2048, "float32", rank=0, world=2)
+    with pytest.raises(RuntimeError, match="one rank"):
+        e.set_maps([0, 1024, 2048], [1.0, 1.0])
+    e.close()
+
+
 # ---- API state behaviour -----------------------------------------------------------------
 def test_solver_state_machine():
     n = 300
