@@ -24,6 +24,7 @@ alg = {"normalize128_kernel": ("8 B read + 16 B written per upper pair", pairs *
        "symv_kernel": ("8 B per element (both triangles)", d * d * 8),
        "gram_kernel": ("the centred matrix once (8 B per element; tiles re-read it from L2 / MALL)", d * d * 8),
        "center_rows_kernel": ("8 B read + 8 B written per element", d * d * 16),
+       "center_rows_reg_kernel": ("8 B read + 8 B written per element", d * d * 16),
        "corr_finalize_kernel": ("8 B read per upper pair of the Gram matrix + 16 B written", pairs * 24),
        "pack_units_from_matrix_kernel": ("8 B read per upper pair + 4 B written", pairs * 12)}
 key = re.compile("(" + "|".join(alg) + r")\\b")
