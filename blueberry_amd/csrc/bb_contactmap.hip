@@ -666,18 +666,32 @@ __global__ __launch_bounds__(256) void center_rows_kernel(const double *__restri
 // kernel above re-read the 200-KB row for the subtraction (counter traffic x1.50 at d = 24,927)
 // behind one wave's worth of dependent 8-byte loads: 3.15 TB/s.  Also writes the zero padding
 // of the row (columns d .. ldx), so the caller clears only the padding rows.
+// (amdgpu_waves_per_eu(4, 4): 128 registers per lane.  Left to itself the compiler aims at 8
+// waves per SIMD, caps the kernel at 64 VGPRs and spills the row -- 208 bytes per lane at
+// CH = 32, which the counters showed as twice the write traffic.)
 template <int CH>
-__global__ __launch_bounds__(1024) void center_rows_reg_kernel(const double *__restrict__ m, int64_t d,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void center_rows_reg_kernel(const double *__restrict__ m, int64_t d,
                                                                double *__restrict__ xc, int64_t ldx) {
     __shared__ double part[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t row = blockIdx.x;
-    const double *p = m + row * d;
+    // a wave owns 64 * CH consecutive columns and walks them in 512-byte steps.  The row is
+    // addressed as a BUFFER of exactly d doubles: a lane beyond the row's end reads 0 and its
+    // store is dropped by the range check, so there is no predicate, no branch and no 64-bit
+    // column index per load to keep (all of which the first version of this kernel had: 4
+    // registers per element, a spill from CH = 24 on).
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(m) + row * d, 0, (int)(d * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        xc + row * ldx, 0, (int)(ldx * 8), 0x00020000);
+    const int c0 = wv * (64 * CH) + lane;
+    const unsigned voff = (unsigned)c0 * 8u;
     double v[CH];
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
-        const int64_t c = tid + 1024 * q;
-        v[q] = c < d ? __builtin_nontemporal_load(p + c) : 0.0;
+        const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(in_rsrc, voff + 512u * q, 0, 2);   // nt
+        v[q] = __hiloint2double((int)w.y, (int)w.x);
     }
     double acc = 0.0;
 #pragma unroll
@@ -690,12 +704,11 @@ __global__ __launch_bounds__(1024) void center_rows_reg_kernel(const double *__r
 #pragma unroll
     for (int k = 0; k < 16; ++k) tot += part[k];      // every thread, the same order
     const double mean = tot / (double)d;
-    double *q_out = xc + row * ldx;
 #pragma unroll
     for (int q = 0; q < CH; ++q) {
-        const int64_t c = tid + 1024 * q;
-        if (c < d) __builtin_nontemporal_store(v[q] - mean, q_out + c);
-        else if (c < ldx) q_out[c] = 0.0;
+        const double o = c0 + 64 * q < (int)d ? v[q] - mean : 0.0;      // d .. ldx: the padding
+        const u32x2_t w = {(unsigned)__double2loint(o), (unsigned)__double2hiint(o)};
+        __builtin_amdgcn_raw_buffer_store_b64(w, out_rsrc, voff + 512u * q, 0, 2);
     }
 }
 
@@ -767,9 +780,6 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__
         const double *qa = pa + buf * (kGT * kGS), *qb = pb + buf * (kGT * kGS);
 #pragma unroll
         for (int kk = 0; kk < kGK / 4; ++kk) {
-#ifdef BB_GRAM_INTERLEAVE
-            if (kk == kGK / 4 - 1) __builtin_amdgcn_sched_barrier(0);
-#endif
             double a[4], b[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -786,19 +796,13 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const double *__restrict__
         // matrix pipe: the loads have long landed).  Left alone the scheduler hoists the
         // stores -- and with them `s_waitcnt vmcnt(0)` -- to four MFMAs below the loads, and
         // every K-tile then waits out the memory latency with the pipe idle: 58.7 TFLOP/s,
-        // 75 % of the peak (round 3); -DBB_GRAM_NO_SCHED restores that for an A/B.
-#if !defined(BB_GRAM_NO_SCHED) && !defined(BB_GRAM_INTERLEAVE)
+        // 75 % of the peak (round 3); -DBB_GRAM_NO_SCHED restores that for an A/B.  (Weaving the
+        // eight stores between the LAST sixteen MFMAs with sched_group_barrier instead: 66.5
+        // against 67.4 TFLOP/s -- the operand reads of the last K-step then issue late.)
+#ifndef BB_GRAM_NO_SCHED
         __builtin_amdgcn_sched_barrier(0);
 #endif
         BB_LSTORE(buf ^ 1);
-#ifdef BB_GRAM_INTERLEAVE
-        // (experiment) the eight LDS stores between the last sixteen MFMAs
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
-        }
-#endif
         __syncthreads();
     }
 #undef BB_GLOAD

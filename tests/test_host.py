@@ -442,27 +442,43 @@ def test_entry_loops_without_python_loops_keep_last_wins():
 
 
 def _kernel_metadata(so_path):
-    """{kernel name: {vgpr, sgpr, scratch}} from the gfx950 code object embedded in a
-    built .so (llvm-readelf --notes of the unbundled .hip_fatbin).  No GPU needed."""
+    """{kernel name: {vgpr, sgpr, scratch}} from EVERY gfx950 code object embedded in a built
+    .so -- one per translation unit (the fat binary holds several offload bundles; the
+    bundler tool unbundles only the first): the AMDGPU ELF images are cut out of the file
+    by their headers and read with llvm-readelf --notes.  No GPU needed."""
+    import struct
     import subprocess
     import tempfile
     llvm = "/opt/rocm/lib/llvm/bin"
-    with tempfile.TemporaryDirectory() as tmp:
-        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "k.co")
-        subprocess.check_call([llvm + "/llvm-objcopy", "-O", "binary",
-                               "--only-section=.hip_fatbin", so_path, fat])
-        subprocess.check_call([llvm + "/clang-offload-bundler", "--type=o",
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
-                               "--input=" + fat, "--output=" + co, "--unbundle"])
-        notes = subprocess.check_output([llvm + "/llvm-readelf", "--notes", co], text=True)
+    blob = open(so_path, "rb").read()
     out = {}
-    for m in re.finditer(r"\.name:\s+(\S+).*?(?=\.name:|\Z)", notes, re.S):
-        blk = m.group(0)
-        if ".vgpr_count" not in blk:
-            continue
-        g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))
-        out[m.group(1)] = {"vgpr": g("vgpr_count"), "sgpr": g("sgpr_count"),
-                           "scratch": g("private_segment_fixed_size")}
+    pos, images = 0, 0
+    with tempfile.TemporaryDirectory() as tmp:
+        while True:
+            pos = blob.find(b"\x7fELF", pos)
+            if pos < 0:
+                break
+            hdr = blob[pos:pos + 64]
+            pos += 4
+            if len(hdr) < 64 or hdr[4] != 2 or struct.unpack_from("<H", hdr, 18)[0] != 224:
+                continue                                   # not a 64-bit EM_AMDGPU image
+            shoff, = struct.unpack_from("<Q", hdr, 40)
+            shentsize, shnum = struct.unpack_from("<HH", hdr, 58)
+            size = shoff + shentsize * shnum
+            co = os.path.join(tmp, "k%d.co" % images)
+            with open(co, "wb") as fh:
+                fh.write(blob[pos - 4:pos - 4 + size])
+            images += 1
+            notes = subprocess.run([llvm + "/llvm-readelf", "--notes", co], text=True,
+                                   capture_output=True).stdout
+            for m in re.finditer(r"\.name:\s+(\S+).*?(?=\.name:|\Z)", notes, re.S):
+                blk = m.group(0)
+                if ".vgpr_count" not in blk:
+                    continue
+                g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", blk).group(1))
+                out[m.group(1)] = {"vgpr": g("vgpr_count"), "sgpr": g("sgpr_count"),
+                                   "scratch": g("private_segment_fixed_size")}
+    out["__images__"] = images
     return out
 
 
@@ -474,7 +490,10 @@ def test_no_product_kernel_spills():
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
         pytest.skip("no LLVM binutils here")
     meta = _kernel_metadata(_lib.LIB_PATH)
-    assert len(meta) > 40, "kernel metadata not found in %s" % _lib.LIB_PATH
+    assert meta.pop("__images__") >= 4, "one code object per .hip translation unit"
+    assert len(meta) > 120, "kernel metadata not found in %s" % _lib.LIB_PATH
+    for name in ("gram_kernel", "normalize128_kernel", "band_count", "downsample_kernel"):
+        assert any(name in k for k in meta), name          # every translation unit was read
     spills = {k: v["scratch"] for k, v in meta.items() if v["scratch"] > 0}
     assert not spills, "kernels with scratch: %r" % spills
     sweeps = {k: v for k, v in meta.items() if "stress_grad_kernel" in k}
