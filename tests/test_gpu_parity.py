@@ -1334,7 +1334,9 @@ def test_several_maps_engine_level_properties():
     sizes = [700, 600]
     off = [0, 1024]
     total = off[1] + sizes[1]
-    tiles = (numpy.array([0, 0, 1, 2], dtype=numpy.int32), numpy.array([0, 1, 1, 2], dtype=numpy.int32))
+    # map 0: blocks 0-1, map 1: blocks 2-3 (bins 1024 .. 1623); device order (J, then I)
+    tiles = (numpy.array([0, 0, 1, 2, 2, 3], dtype=numpy.int32),
+             numpy.array([0, 1, 1, 2, 3, 3], dtype=numpy.int32))
     e = HipEngine(total, "float32", tiles=tiles)
     e.set_maps(off + [total], [1.0 / 1400, 1.0 / 1200])
     ws = [_oracle.wish_from_coords(_oracle.random_walk(n, seed=q)) for q, n in enumerate(sizes)]
