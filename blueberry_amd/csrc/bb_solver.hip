@@ -142,7 +142,7 @@ int dev_alloc(T **p, int64_t count) {
 // 8-KiB window one wave per SIMD already keeps enough bytes in flight, and fewer,
 // longer chunks mean fewer column-partial slots and less prologue per byte; two
 // waves per SIMD overlap one wave's VALU work with the other's waits.  With the
-// current kernel (profiles/r01_sweep_wpc.txt): 8/CU is 2-4 % faster from ~150k units
+// current kernel (profiles/archive/r01_sweep_wpc.txt): 8/CU is 2-4 % faster from ~150k units
 // per rank (N=24,926) up, 4 and 8 tie at 77k units (1/8 of the N=50k matrix, where
 // 4 means half as many column partials for the reduce), 6 is always worse (a
 // workgroup count that is not a multiple of the CU count), 16 is 2 % slower.
@@ -160,7 +160,7 @@ int waves_per_cu(int64_t n_local) {
 }
 
 // Largest map (bins) that iterates on the row-owner path.  Measured on MI355X
-// (tools/small_n_timing.py, profiles/r02_small_n.txt); BB_ROW_OWNER_MAX overrides,
+// (tools/small_n_timing.py, profiles/archive/r02_small_n.txt); BB_ROW_OWNER_MAX overrides,
 // 0 turns the path off.
 int64_t row_owner_max() {
     const char *e = getenv("BB_ROW_OWNER_MAX");
@@ -220,7 +220,7 @@ int build_indices(bb_solver *s) {
         // sweep at N=50k) unless this rank's units fit the 256-MB Infinity Cache: then they
         // are read again from it on the next iteration, and plain loads keep them there
         // (N=8,000 / 10,000: kernel -8 %, step -3.5 / -6 %; equal at N=12,000 = 288 MB;
-        // non-temporal 3-4 % better at N=17,700; profiles/r02_nt_ab.txt).  BB_NT=0|1 overrides.
+        // non-temporal 3-4 % better at N=17,700; profiles/archive/r02_nt_ab.txt).  BB_NT=0|1 overrides.
         const char *e = getenv("BB_NT");
         s->nontemporal = e ? atoi(e) != 0 : s->n_local * bb::kUnitBytes > ((int64_t)240 << 20);
     }
@@ -308,7 +308,7 @@ int build_indices(bb_solver *s) {
     // the longest list has at most 128 chunks (N <= ~35k on one rank, every 1/8 share of
     // N=50k) ONE launch sums every list whole; beyond that lists are cut into slices that a
     // first launch sums in parallel into `part2`, which the final stage then combines.
-    // Measured (profiles/r02_reduce_ab.txt): one launch saves 1-1.6 us per iteration at
+    // Measured (profiles/archive/r02_reduce_ab.txt): one launch saves 1-1.6 us per iteration at
     // N=17,700 / 24,926, nothing at 50k, and loses 1-2 us at 61,914 -- the reduce is bound by
     // the 20-56 MB of partials the sweep has just written, not by its launches.
     // BB_REDUCE_SINGLE_MAX overrides.

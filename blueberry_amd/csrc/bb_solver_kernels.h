@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(64 * WPB, (Lay<T, W>::MIN_WG)) void stress_grad_ker
                 // for after the window -- so the compiler's wait counts inside the loop
                 // are those of the back edge alone, which is what round 1 peeled the first
                 // iteration for.  Same speed as the peeled form at every size
-                // (profiles/r02_peel_ab.txt), a third less code.
+                // (profiles/archive/r02_peel_ab.txt), a third less code.
                 __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
                 do {
                     unit_step(u, std::false_type{});

@@ -26,3 +26,10 @@ for run in (1, 2):
     print("run %d: from_triples %.0f ms, normalize %.1f ms, filter %.1f ms (-> %d bins), fit(K=%d, spectral start) %.0f ms; total %.0f ms; "
           "stress %.3e -> %.3e" % (run, d[0], d[1], d[2], cm.shape[0], K, d[3], sum(d), s.stress_[0], s.stress_[-1]))
     del cm, s
+    # the same input without the dense matrix: fit_triples (bins, cleans and scatters the
+    # triples on the device into the occupied tiles only)
+    t0 = time.perf_counter()
+    s2 = bb.StructureSolver(n_iter=K, dtype="float32").fit_triples(triples, res, n_bins, KRnorm=kr, KRexpected=ke)
+    print("run %d: fit_triples(K=%d), whole call %.0f ms; stress %.3e -> %.3e"
+          % (run, K, (time.perf_counter() - t0) * 1e3, s2.stress_[0], s2.stress_[-1]))
+    del s2

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Throughput and roofline fraction over problem sizes, fp32 and fp64, one line each
-# (bench.py, 60 timed steps, settle phase on): the table in profiles/r02_size_sweep.txt.
+# (bench.py, 60 timed steps, settle phase on): the table in profiles/archive/r02_size_sweep.txt.
 out=gpurun_out/size_sweep.txt; : > $out
 for dt in float32 float64; do
   for n in ${SWEEP_BINS:-963 2000 4096 5000 8000 12000 17700 24926 35000 50000 61914 90000}; do
