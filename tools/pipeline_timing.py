@@ -23,9 +23,12 @@ for run in (1, 2):
     cm.filter(0.0); t.append(time.perf_counter())
     s = bb.StructureSolver(n_iter=K, dtype="float32").fit(cm); t.append(time.perf_counter())
     d = numpy.diff(t) * 1e3
-    print("run %d: from_triples %.0f ms, normalize %.1f ms, filter %.1f ms (-> %d bins), fit(K=%d, spectral start) %.0f ms; total %.0f ms; "
+    print("run %d: from_triples %.0f ms, normalize %.1f ms, filter %.1f ms (-> %d bins), fit(K=%d, seeded random start) %.0f ms; total %.0f ms; "
           "stress %.3e -> %.3e" % (run, d[0], d[1], d[2], cm.shape[0], K, d[3], sum(d), s.stress_[0], s.stress_[-1]))
     del cm, s
+# (after both runs of the pipeline: an allocation in between would change which blocks the
+# runtime hands back to the second run, and a FRESH 5-GB block costs 0.2-0.35 s to first touch)
+for run in (1, 2):
     # the same input without the dense matrix: fit_triples (bins, cleans and scatters the
     # triples on the device into the occupied tiles only)
     t0 = time.perf_counter()
