@@ -866,7 +866,9 @@ class StructureSolver(object):
         them, every map with its own step (`lr='auto'`: 1 / (2 n_m)) and its own stress
         history.  Same iteration as `fit()` map by map; results agree with the single fits
         to rounding (1e-5 fp32 / 1e-12 fp64: the partial sums are cut differently), not bit
-        for bit.  One rank only: on several GPUs give every rank maps of its own.
+        for bit.  Inside a torch.distributed job the maps are dealt to the ranks by size,
+        every rank solves its own in one solver on its GPU, and every rank gets all results
+        (`ranks_of_maps_` tells who solved what): no exchange during the iterations.
 
         maps: sequence of ContactMaps (resident ones are packed device to device), square
         ndarrays or anything `numpy.asarray` takes.  inits: None, or one (n_m, 3) start per
@@ -882,6 +884,43 @@ class StructureSolver(object):
             inits = [None] * len(maps)
         if len(inits) != len(maps):
             raise ValueError("inits needs one entry per map")
+        rank, world = _dist_state(self.distributed)
+        if world > 1:
+            # Several GPUs: the maps are independent problems, so every rank solves maps of its
+            # own (dealt by size, largest first, to the rank with the least pairs so far) and
+            # the results are gathered -- no exchange during the iterations at all.
+            import torch.distributed as dist
+            sizes = [int(getattr(X, "shape", numpy.shape(getattr(X, "matrix", X)))[0]) for X in maps]
+            load, mine = [0] * world, [[] for _ in range(world)]
+            for m in sorted(range(len(maps)), key=lambda q: (-sizes[q], q)):
+                r = min(range(world), key=lambda q: (load[q], q))
+                load[r] += sizes[m] * sizes[m]
+                mine[r].append(m)
+            part = None
+            if mine[rank]:
+                local = StructureSolver(n_iter=self.n_iter, lr=self.lr, dtype=self.dtype,
+                                        alpha=self.alpha, kind=self.kind, seed=self.seed,
+                                        device=self._pick_device(world), distributed=False,
+                                        engine=self._engine_factory, momentum=self.momentum,
+                                        init=self.init, tol=self.tol, check_every=self.check_every)
+                local._fit_many_local([maps[m] for m in mine[rank]], [inits[m] for m in mine[rank]])
+                part = (mine[rank], local.structures_, local.stresses_, local.lrs_)
+            parts = [None] * world
+            dist.all_gather_object(parts, part)
+            n = len(maps)
+            self.structures_, self.stresses_, self.lrs_ = [None] * n, [None] * n, [None] * n
+            for p in parts:
+                if p is not None:
+                    for k, m in enumerate(p[0]):
+                        self.structures_[m], self.stresses_[m], self.lrs_[m] = p[1][k], p[2][k], p[3][k]
+            self.n_bins_many_ = sizes
+            self.n_iter_ = max(int(h.shape[0]) for h in self.stresses_)
+            self.ranks_of_maps_ = [next(r for r in range(world) if m in mine[r]) for m in range(n)]
+            return self
+        return self._fit_many_local(maps, inits)
+
+    def _fit_many_local(self, maps, inits):
+        """fit_many on this rank's GPU (see fit_many)."""
         sizes, srcs = [], []
         for X in maps:
             if getattr(X, "is_resident", False):

@@ -28,6 +28,8 @@ class OracleEngine(object):
         _lib.check(lib.bb_layout_rank_units(self.info.n_units, rank, world, ub, ue))
         self.u_begin, self.u_end = int(ub.value), int(ue.value)
         self.oracle = _oracle.load()
+        self.tiles_arg = tiles
+        self.device = device
         self.exch = numpy.zeros(3 * self.info.n_pad + 2)
         self.hist = []
         self.mu = 0.0
@@ -70,12 +72,50 @@ class OracleEngine(object):
         self.hist.append(self.exch[-2] + self.exch[-1])
 
     def iterate(self, iters, lr):
+        if getattr(self, "maps", None):
+            return self._iterate_maps(iters, lr)
         for _ in range(iters):
             self.grad()
             self.apply(lr)
 
     def stress_history(self):
         return numpy.array(self.hist)
+
+    # -- several maps in one solver (the host logic of StructureSolver.fit_many on CPU) --------
+    def set_maps(self, bin_begin, lr_scale):
+        assert self.world == 1
+        self.maps = [(int(a), None, float(s)) for a, s in zip(bin_begin[:-1], lr_scale)]
+        self.n_maps = len(self.maps)
+        vw = self.info.vw
+        assert all(a % vw == 0 for a, _, _ in self.maps) and int(bin_begin[-1]) == self.n_bins
+        # what bb_solver_create / bb_solver_set_maps check of the tile list the host wrote:
+        # strictly ordered by (J, I), I <= J, and no tile joins two maps
+        ti, tj = (numpy.asarray(t, dtype=numpy.int64) for t in self.tiles_arg)
+        key = tj * self.info.n_blocks + ti
+        assert (ti <= tj).all() and (numpy.diff(key) > 0).all() and tj.max() < self.info.n_blocks
+        starts = numpy.asarray([a for a, _, _ in self.maps]) // vw
+        assert (numpy.searchsorted(starts, ti, side="right") ==
+                numpy.searchsorted(starts, tj, side="right")).all()
+
+    def set_wish_dense_block(self, matrix, bin_offset, kind, alpha):
+        m = numpy.ascontiguousarray(matrix, dtype=numpy.float64)
+        w = self.oracle.counts_to_wish(m, alpha) if kind == "counts" else m
+        for q, (a, _, s) in enumerate(self.maps):
+            if a == int(bin_offset):
+                self.maps[q] = (a, w, s)
+                return
+        raise ValueError("no map starts at bin %d" % bin_offset)
+
+    def _iterate_maps(self, iters, lr):
+        for _ in range(iters):
+            row = []
+            for a, w, scale in self.maps:
+                n = w.shape[0]
+                s, g = self.oracle.stress_grad(w, self.X[a:a + n], f64=self.dtype == "float64")
+                self.V[a:a + n] = self.mu * self.V[a:a + n] - lr * scale * g
+                self.X[a:a + n] += self.V[a:a + n]
+                row.append(s)
+            self.hist.extend(row)
 
     def matvec_sq(self, x):
         """(D o D) @ x restricted to the pairs this rank's units own (numpy)."""

@@ -169,6 +169,56 @@ def test_multi_rank_spectral_start_control_flow(fail_rank):
     assert numpy.array_equal(results[0][2], results[1][2])         # replicas identical
 
 
+# ---- fit_many on several ranks: every rank solves maps of its own ----------------------------
+def _many_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import blueberry_amd as bb
+        from tests import _oracle
+        from tests._engines import OracleEngine
+        sizes = [300, 90, 640, 200, 515]
+        mats = [_oracle.wish_from_coords(_oracle.random_walk(n, seed=q_)) for q_, n in enumerate(sizes)]
+        s = bb.StructureSolver(n_iter=3, dtype="float64", kind="wish", seed=2,
+                               engine=OracleEngine).fit_many(mats)      # picks up the gloo job
+        q.put((rank, s.structures_, s.stresses_, s.ranks_of_maps_))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, traceback.format_exc(), None, None))
+
+
+def test_fit_many_deals_the_maps_to_the_ranks(oracle):
+    """Several GPUs: the maps are independent, so every rank solves maps of its own (dealt by
+    size) and all ranks get all results -- equal to the oracle's solve of each map."""
+    import torch.multiprocessing as mp
+    from tests import _oracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_many_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=240) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert not isinstance(r[1], str), r[1]
+    sizes = [300, 90, 640, 200, 515]
+    owners = results[0][3]
+    assert owners == results[1][3] and set(owners) == {0, 1}
+    assert owners[2] != owners[4]                    # the two largest maps go to different ranks
+    for m, n in enumerate(sizes):
+        w = _oracle.wish_from_coords(_oracle.random_walk(n, seed=m))
+        x0 = numpy.random.default_rng(2).standard_normal((n, 3))
+        X, h = oracle.solve(w, x0, 3, 1.0 / (2 * n))
+        for r in results:
+            assert numpy.array_equal(r[1][m], X) and numpy.array_equal(r[2][m], h)
+
+
 # ---- select_exchange: the decision logic, with a scripted engine -----------------
 class _ScriptedEngine(object):
     """Stands in for HipEngine: records what select_exchange does to it and lets a

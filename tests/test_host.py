@@ -205,6 +205,38 @@ def test_spectral_init_on_two_and_three_bins(n):
     assert numpy.abs(_oracle.wish_from_coords(s.structure_) - w).max() < 1e-9 * w.max()
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_fit_many_host_logic_with_the_oracle_engine(oracle, dtype):
+    """StructureSolver.fit_many's own work -- the joint layout (every map at a multiple of the
+    tile edge: 128 for a small fp64 job, else 512), the tile list it hands to the engine
+    (strictly ordered, no tile joining two maps: checked by the test engine as
+    bb_solver_set_maps checks it), per-map steps, starts and results -- with each map's
+    compute played by the oracle: every map must come out as the oracle's solve of that map."""
+    from tests._engines import OracleEngine
+    from tests import _oracle
+    sizes = [130, 700, 513, 2]
+    mats = [_oracle.wish_from_coords(_oracle.random_walk(n, seed=q)) + (0 if n > 2 else 1.0 - numpy.eye(2))
+            for q, n in enumerate(sizes)]
+    x0 = [_oracle.noisy_init(_oracle.random_walk(n, seed=q), seed=9) for q, n in enumerate(sizes)]
+    s = bb.StructureSolver(n_iter=4, dtype=dtype, kind="wish", engine=OracleEngine,
+                           distributed=False, momentum=0.3).fit_many(mats, inits=x0)
+    assert s.n_bins_many_ == sizes and s.n_iter_ == 4
+    for q, n in enumerate(sizes):
+        X, h = oracle.solve_momentum(mats[q], x0[q], 4, 1.0 / (2 * n), 0.3, f64=dtype == "float64")
+        assert numpy.array_equal(s.structures_[q], X) and numpy.array_equal(s.stresses_[q], h)
+    # default starts are fit()'s; a ContactMap is taken by its matrix
+    a = bb.StructureSolver(n_iter=2, dtype=dtype, kind="wish", seed=5, engine=OracleEngine,
+                           distributed=False).fit_many([mats[0], bb.ContactMap.from_matrix(mats[1])])
+    for q in (0, 1):
+        one = bb.StructureSolver(n_iter=2, dtype=dtype, kind="wish", seed=5, engine=OracleEngine,
+                                 distributed=False).fit(mats[q])
+        assert numpy.array_equal(a.structures_[q], one.structure_)
+    with pytest.raises(ValueError):
+        bb.StructureSolver(engine=OracleEngine, distributed=False).fit_many(mats, inits=x0[:2])
+    with pytest.raises(ValueError):
+        bb.StructureSolver(engine=OracleEngine, distributed=False).fit_many([numpy.zeros((1, 1))])
+
+
 def test_count_band_regions_input_checks():
     with pytest.raises(ValueError):
         bb.band._as_regions(numpy.zeros((2, 2)))
