@@ -1334,6 +1334,21 @@ def test_fit_many_equals_the_oracle_map_by_map(oracle, dtype, tol, mu):
         assert _rel(s.structures_[q], one.structure_) < tol
 
 
+@pytest.mark.parametrize("dtype,tol", [("float64", 1e-12), ("float32", 1e-5)])
+def test_fit_many_small_maps(oracle, dtype, tol):
+    """A batch small enough for the narrow fp64 layout (128-wide tiles, the generic unit body)
+    and, in fp32, small enough that a single map of that size would take the row-owner path:
+    the batch runs on the sweep either way and each map equals the oracle's solve."""
+    sizes, k = [300, 500, 200, 129], 8
+    mats = [_oracle.wish_from_coords(_oracle.random_walk(n, seed=40 + q)) for q, n in enumerate(sizes)]
+    x0s = [_oracle.noisy_init(_oracle.random_walk(n, seed=40 + q), seed=3) for q, n in enumerate(sizes)]
+    s = bb.StructureSolver(n_iter=k, dtype=dtype, kind="wish").fit_many(mats, inits=x0s)
+    for q, n in enumerate(sizes):
+        X_ref, h_ref = oracle.solve(mats[q], x0s[q], k, 1.0 / (2 * n), f64=dtype == "float64")
+        assert numpy.abs(s.stresses_[q] / h_ref - 1).max() < tol, (q, dtype)
+        assert _rel(s.structures_[q], X_ref) < tol, (q, dtype)
+
+
 def test_fit_many_defaults_early_stop_and_spectral():
     sizes = [600, 1500, 900]
     mats = [_oracle.wish_from_coords(_oracle.random_walk(n, seed=30 + q)) for q, n in enumerate(sizes)]
