@@ -361,7 +361,9 @@ int build_indices(bb_solver *s) {
     const int64_t es = bb::elem_size(s->dtype);
     s->hist_cap = kHistCap;
     if (s->row_owner) {
-        s->full_ld = bb::round_up(s->L.n_bins, kRowTrip);
+        // a whole number of trips per row: 256 columns in fp32, 128 in fp64 (RowTrip<T>::COLS)
+        s->full_ld = bb::round_up(s->L.n_bins, s->dtype == BB_F32 ? RowTrip<float>::COLS
+                                                                  : RowTrip<double>::COLS);
         // waves per row: enough of them that a small map still covers the chip with
         // about 16 waves per CU (N=963: 4 per row); BB_ROW_OWNER_WPR overrides
         const char *ew = getenv("BB_ROW_OWNER_WPR");

@@ -2070,7 +2070,22 @@ __device__ __forceinline__ void pair_row(T delta, T xi, T yi, T zi, T xj, T yj, 
     gz = fma(coef, dz, gz);
 }
 
-constexpr int kRowTrip = 128;   // columns per loop trip of a wave: 2 per lane
+// columns per loop trip of a wave: one 16-byte load per lane = 4 (fp32) / 2 (fp64) columns.
+// Round 4: per pair the kernel issued one 4-byte (8-byte) load of the matrix and three scalar
+// loads of the partner's coordinates.  A lane now takes 4 (2) CONSECUTIVE columns: one 16-byte
+// load of the row and three 16-byte loads of the 12 (6) contiguous coordinates of those
+// columns -- one load per pair (two in fp64) instead of four: fp64 -9 % at N=963, -12 % at
+// 2,500, -19 % at 4,096 (28.4 -> 23.0 us); fp32 -4 % at 2,500, -8 % at 4,096
+// (profiles/r04_row_owner_ab.txt; -DBB_ROW_OWNER_SCALAR keeps the old trip for the A/B).
+// Packed fp32 pair math on top of it (v_pk_* straight on the AoS register pairs) changed
+// nothing: from N ~ 4,000 the kernel moves both triangles at ~5 TB/s and that is its bound.
+#ifdef BB_ROW_OWNER_SCALAR
+constexpr int kRowTrip = 128;
+template <typename T> struct RowTrip { static constexpr int COLS = 128; };
+#else
+constexpr int kRowTrip = 256;   // (the larger of the two: what `ld` is rounded up to)
+template <typename T> struct RowTrip { static constexpr int COLS = 64 * (16 / (int)sizeof(T)); };
+#endif
 
 // WPR waves share one row (1, 2 or 4: the host picks it so that a small map still
 // puts >= 16 waves on every CU): wave part p takes the 128-column trips p, p + WPR, ...;
@@ -2105,15 +2120,33 @@ __global__ __launch_bounds__(256) void row_owner_kernel(
     if (i < n) {
         xi = Xin[3 * (int64_t)i]; yi = Xin[3 * (int64_t)i + 1]; zi = Xin[3 * (int64_t)i + 2];
         const T *row = full + (int64_t)i * ld;
-        const int trips = ((int)(ld / kRowTrip) - part + WPR - 1) / WPR;   // trips part, part + WPR, ...
+        constexpr int COLS = RowTrip<T>::COLS;
+        const int trips = ((int)(ld / COLS) - part + WPR - 1) / WPR;   // trips part, part + WPR, ...
         auto trip = [&](int tr) __attribute__((always_inline)) {
-            const int c = (part + tr * WPR) * kRowTrip;
+#ifdef BB_ROW_OWNER_SCALAR
+            const int c = (part + tr * WPR) * COLS;
 #pragma unroll
-            for (int u = 0; u < kRowTrip / 64; ++u) {
+            for (int u = 0; u < COLS / 64; ++u) {
                 const int j = c + 64 * u + lane;
                 const T *xj = Xin + 3 * (int64_t)j;
                 pair_row<T>(row[j], xi, yi, zi, xj[0], xj[1], xj[2], gx, gy, gz, s);
             }
+#else
+            using Vec = typename Traits<T>::Vec;
+            const int c = (part + tr * WPR) * COLS + lane * Traits<T>::VPL;
+            const Vec dv = *reinterpret_cast<const Vec *>(row + c);
+            const Vec *px = reinterpret_cast<const Vec *>(Xin + 3 * (int64_t)c);
+            const Vec a = px[0], b = px[1], q = px[2];
+            if constexpr (sizeof(T) == 4) {      // x0 y0 z0 x1 | y1 z1 x2 y2 | z2 x3 y3 z3
+                pair_row<T>(dv.x, xi, yi, zi, a.x, a.y, a.z, gx, gy, gz, s);
+                pair_row<T>(dv.y, xi, yi, zi, a.w, b.x, b.y, gx, gy, gz, s);
+                pair_row<T>(dv.z, xi, yi, zi, b.z, b.w, q.x, gx, gy, gz, s);
+                pair_row<T>(dv.w, xi, yi, zi, q.y, q.z, q.w, gx, gy, gz, s);
+            } else {                             // x0 y0 | z0 x1 | y1 z1
+                pair_row<T>(dv.x, xi, yi, zi, a.x, a.y, b.x, gx, gy, gz, s);
+                pair_row<T>(dv.y, xi, yi, zi, b.y, q.x, q.y, gx, gy, gz, s);
+            }
+#endif
         };
         // fp32: 4 trips (8 pairs per lane) in flight; fp64: unrolling costs more in
         // registers than it hides (N=2,500: 18.3 us per iteration unrolled, 14.4 rolled)
