@@ -2,8 +2,6 @@
 // arithmetic of libblueberry_hip.so (include/blueberry_hip.h).
 #include "bb_common.h"
 
-#include <stdlib.h>
-
 #include <map>
 #include <mutex>
 #include <vector>
@@ -66,74 +64,6 @@ void release_stream(int device, hipStream_t stream) {
         }
     }
     (void)hipStreamDestroy(stream);    // pool full, or the stream is in an error state
-}
-
-namespace {
-struct CachedBlock { void *p; size_t bytes; };
-std::mutex g_block_mu;
-std::map<int, std::vector<CachedBlock>> g_blocks;
-bool block_pool_on() {
-    static const bool on = [] { const char *e = getenv("BB_BLOCK_POOL"); return !(e && atoi(e) == 0); }();
-    return on;
-}
-}  // namespace
-
-hipError_t block_alloc(int device, size_t bytes, void **ptr, size_t *capacity) {
-    if (bytes == 0) bytes = 1;
-    *ptr = nullptr;
-    *capacity = bytes;
-    if (block_pool_on() && bytes >= kPoolMinBytes) {
-        std::lock_guard<std::mutex> lock(g_block_mu);
-        auto &v = g_blocks[device];
-        int best = -1;
-        for (int i = 0; i < (int)v.size(); ++i)       // the smallest cached block that fits
-            if (v[i].bytes >= bytes && v[i].bytes / 4 <= bytes && (best < 0 || v[i].bytes < v[best].bytes))
-                best = i;
-        if (best >= 0) {
-            *ptr = v[best].p;
-            *capacity = v[best].bytes;
-            v.erase(v.begin() + best);
-            return hipSuccess;
-        }
-    }
-    hipError_t e = hipMalloc(ptr, bytes);
-    if (e == hipErrorOutOfMemory && block_pool_on()) {
-        // the cache may be what is in the way: give it back and try once more
-        (void)hipGetLastError();
-        block_pool_release(device);
-        e = hipMalloc(ptr, bytes);
-    }
-    return e;
-}
-
-void block_free(int device, void *ptr, size_t capacity) {
-    if (!ptr) return;
-    if (block_pool_on() && capacity >= kPoolMinBytes) {
-        std::lock_guard<std::mutex> lock(g_block_mu);
-        auto &v = g_blocks[device];
-        if ((int)v.size() < kPooledBlocks) {
-            v.push_back({ptr, capacity});
-            return;
-        }
-        int smallest = 0;
-        for (int i = 1; i < (int)v.size(); ++i)
-            if (v[i].bytes < v[smallest].bytes) smallest = i;
-        if (v[smallest].bytes < capacity) {           // keep the larger ones
-            void *out = v[smallest].p;
-            v[smallest] = {ptr, capacity};
-            ptr = out;
-        }
-    }
-    (void)hipFree(ptr);
-}
-
-void block_pool_release(int device) {
-    std::vector<CachedBlock> out;
-    {
-        std::lock_guard<std::mutex> lock(g_block_mu);
-        out.swap(g_blocks[device]);
-    }
-    for (auto &b : out) (void)hipFree(b.p);
 }
 
 }  // namespace bb

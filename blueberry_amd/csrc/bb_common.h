@@ -71,22 +71,6 @@ int enter_device(int device);
 hipError_t acquire_stream(int device, hipStream_t *out);
 void release_stream(int device, hipStream_t stream);
 
-// Large device blocks (a ContactMap's matrix, a solver's arena, resident triples) come from a
-// small per-device cache of freed blocks: on this platform the first touch of a FRESHLY mapped
-// multi-GB block costs 0.2-1 s (tools/alloc_probe.py, tools/alloc_seq_probe.py), and a
-// genome-wide loop -- one ContactMap and one solver alive at a time, each of another size --
-// paid it erratically (0.7-1.0 s per pass over 23 chromosomes, as much as the compute).
-// block_alloc hands out a cached block that fits (its capacity may exceed the request by up
-// to 4x), else hipMalloc; block_free keeps up to kPooledBlocks of the largest freed blocks
-// per device and gives the rest back.  Requests under kPoolMinBytes bypass the cache.
-// BB_BLOCK_POOL=0 turns it off; block_pool_release(device) frees what is cached
-// (bb_cm_release_scratch).  Contents of a handed-out block are undefined, as hipMalloc's.
-constexpr size_t kPoolMinBytes = (size_t)32 << 20;
-constexpr int kPooledBlocks = 2;
-hipError_t block_alloc(int device, size_t bytes, void **ptr, size_t *capacity);
-void block_free(int device, void *ptr, size_t capacity);
-void block_pool_release(int device);
-
 // Kernel launch that hands back the launch's OWN status (hipLaunchKernel returns it).
 // The library never reads hipGetLastError(): that word is per-thread, sticky, and shared
 // with every other HIP user of the calling thread (torch, RCCL), so a launch check made

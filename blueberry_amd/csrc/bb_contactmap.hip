@@ -26,7 +26,6 @@ struct bb_cm {
     int device = 0;
     int64_t d = 0;            // current edge (shrinks in filter)
     double *m = nullptr;      // (d, d) row-major, resident
-    size_t m_capacity = 0;    // bytes of the block behind m (bb::block_alloc: may exceed d * d * 8)
     hipStream_t stream = nullptr;
     // grow-only scratch of the symmetric matrix-vector product (symv_upper_kernel): the work
     // list and the row / column partial sums; made by the first product, kept with the handle
@@ -34,6 +33,8 @@ struct bb_cm {
     size_t sv_bytes = 0;
     int64_t sv_d = -1;        // the edge the work list was built for
     int sv_items = 0;
+    // scratch of bb_cm_correlation (centred rows + Gram matrix), kept between calls: the
+    // first touch of a fresh matrix-sized allocation costs 0.2-0.35 s on this platform
 };
 
 namespace {
@@ -1414,7 +1415,6 @@ int bb_cm_release_scratch(int device) {
     (void)hipFree(sc->buf);
     sc->buf = nullptr;
     sc->bytes = 0;
-    bb::block_pool_release(device);      // ... and the freed matrix / arena blocks kept for reuse
     return BB_OK;
 }
 

@@ -48,7 +48,6 @@ struct bb_solver {
     int chunk_q = 0, chunk_r = 0;  // units per wave: n_local = n_waves * q + r
     bool nontemporal = true;
     char *d_arena = nullptr;       // the one allocation behind every d_* below but d_exch / peer / mv_in
-    size_t arena_capacity = 0;     // bytes of that block (bb::block_alloc)
     int2 *d_wave_slots = nullptr;  // per wave {first private slot, the workgroup's shared slot}
     int lds_wave_floats = 0;       // LDS region per wave of the sweep, in 4-byte words
     double *d_stresspart = nullptr;
@@ -405,13 +404,7 @@ int build_indices(bb_solver *s) {
         }
         size_t total = 0;
         for (auto &w : want) total += (w.second + 255) & ~(size_t)255;
-        {
-            void *blk = nullptr;
-            const hipError_t e = bb::block_alloc(s->device, total, &blk, &s->arena_capacity);
-            if (e != hipSuccess)
-                return bb::fail(BB_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
-            s->d_arena = (char *)blk;
-        }
+        BB_TRY(dev_alloc(&s->d_arena, (int64_t)total));
         size_t off = 0;
         for (auto &w : want) {
             *w.first = s->d_arena + off;
@@ -909,7 +902,7 @@ int bb_solver_destroy(bb_solver *s) {
     hipFree(s->d_peer_state);
     hipFree(s->d_peer_counter);
     for (hipEvent_t e : s->ev) hipEventDestroy(e);
-    bb::block_free(s->device, s->d_arena, s->arena_capacity);
+    hipFree(s->d_arena);
     hipFree(s->d_blk_scale);
     hipFree(s->d_map_ptr);
     hipFree(s->d_map_idx);
@@ -1198,7 +1191,6 @@ struct bb_triples {
     int64_t n = 0, st = 3, sc = 1;      // element (t, c) at d[t * st + c * sc]
     double resolution = 1.0;
     double *d = nullptr;
-    size_t capacity = 0;
 };
 
 int bb_triples_create(bb_triples **out, const double *triples, int64_t n, int32_t resolution,
@@ -1214,20 +1206,14 @@ int bb_triples_create(bb_triples **out, const double *triples, int64_t n, int32_
     t->n = n;
     t->resolution = (double)resolution;
     if (row_major) { t->st = 3; t->sc = 1; } else { t->st = 1; t->sc = n; }
-    int rc = BB_OK;
-    {
-        void *blk = nullptr;
-        if (bb::block_alloc(device, (size_t)std::max<int64_t>(3 * n, 1) * 8, &blk, &t->capacity) != hipSuccess)
-            rc = bb::fail(BB_ERR_NOMEM, "bb_triples_create: out of device memory");
-        t->d = (double *)blk;
-    }
+    int rc = dev_alloc(&t->d, 3 * n);
     if (rc == BB_OK && n > 0) {
         const hipError_t e = hipMemcpy(t->d, triples, (size_t)n * 24, hipMemcpyHostToDevice);
         if (e != hipSuccess)
             rc = bb::fail(BB_ERR_HIP, std::string("bb_triples_create: ") + hipGetErrorString(e));
     }
     if (rc != BB_OK) {
-        bb::block_free(device, t->d, t->capacity);
+        hipFree(t->d);
         delete t;
         return rc;
     }
@@ -1238,7 +1224,7 @@ int bb_triples_create(bb_triples **out, const double *triples, int64_t n, int32_
 int bb_triples_destroy(bb_triples *t) {
     if (!t) return BB_OK;
     hipSetDevice(t->device);
-    bb::block_free(t->device, t->d, t->capacity);
+    hipFree(t->d);
     delete t;
     (void)hipGetLastError();
     return BB_OK;

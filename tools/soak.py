@@ -14,9 +14,6 @@ from tests import _oracle
 
 
 def free_mb():
-    # (the library keeps up to two freed blocks >= 32 MiB per device for reuse: give them
-    # back first, or they read as a leak)
-    bb._lib.load().bb_cm_release_scratch(0)
     torch.cuda.synchronize()
     return torch.cuda.mem_get_info(0)[0] / 2**20
 
