@@ -68,6 +68,13 @@ def test_compute_fails_loudly_without_gpu():
         cm.eigenvector()
     with pytest.raises(RuntimeError, match="HIP device"):
         bb.ContactMap.from_triples(numpy.array([[0.0, 5000.0, 3.0]]), 5000, 4)
+    # the round-4 entry points: several maps in one solver, triples resident on the device
+    with pytest.raises(RuntimeError, match="HIP device"):
+        bb.StructureSolver(n_iter=1).fit_many([numpy.ones((4, 4)), numpy.ones((5, 5))])
+    with pytest.raises(RuntimeError, match="HIP device"):
+        bb.StructureSolver(n_iter=1).fit_triples(numpy.array([[0.0, 5000.0, 3.0]]), 5000, 4)
+    with pytest.raises(ValueError):      # (argument checks come before the device is needed)
+        bb.StructureSolver(n_iter=1).fit_triples(numpy.zeros((3, 2)), 5000, 4)
     assert cm.matrix.shape == (3, 3)     # the host copy was never lost
     n = _lib.ctypes.c_int(5)
     assert _lib.load().bb_device_count(n) == _lib.BB_ERR_HIP and n.value == 0
