@@ -569,3 +569,74 @@ def test_multi_rank_spectral_start_stays_on_the_device(dtype, tol, world, form, 
     d = _oracle.wish_from_coords(Xs[0])
     assert numpy.abs(d - w).max() < (1e-6 if dtype == "float64" else 1e-3) * w.max()
     assert all(numpy.array_equal(h, hs[0]) for h in hs) and hs[0].shape == (3,)
+
+
+def _worker_spectral_fit(rank, world, port, n, dtype, comm, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["BB_COMM"] = comm
+        os.environ["BB_PEER_TIMEOUT_MS"] = "20000"
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import blueberry_amd as bb
+        from blueberry_amd import solver
+        from tests import _oracle
+        calls = {"host_form": 0}
+        host_form = solver.spectral_init
+
+        def counted(*a, **k):
+            calls["host_form"] += 1
+            return host_form(*a, **k)
+
+        solver.spectral_init = counted
+        xs = _oracle.random_walk(n)
+        w = _oracle.wish_from_coords(xs)
+        s = bb.StructureSolver(n_iter=3, dtype=dtype, kind="wish", device=0, init="spectral",
+                               seed=0).fit(w)
+        q.put((rank, s.structure_, s.stress_, s.exchange_, calls["host_form"]))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, traceback.format_exc(), None, None, None))
+
+
+@pytest.mark.parametrize("dtype,tol,world,comm", [("float64", 1e-9, 2, "peer"),
+                                                   ("float32", 1e-3, 3, "peer"),
+                                                   ("float64", 1e-9, 2, "host")])
+def test_fit_with_spectral_start_across_processes(dtype, tol, world, comm):
+    """The whole Python path on real processes (sharing the test box's GPU, arenas mapped
+    through HIP IPC): `fit(init='spectral')` chooses its exchange first, then computes the
+    classical-MDS start ON THE DEVICE on every rank when the exchange sums there (peer), the
+    per-rank products going through it -- and through the host-driven loop when it does not
+    (gloo, host-staged).  Every rank ends with the start one process computes alone and the
+    same three iterations from it."""
+    import torch.multiprocessing as mp
+    import blueberry_amd as bb
+    from tests import _oracle
+    n = 2300
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_spectral_fit, args=(r, world, port, n, dtype, comm, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert not isinstance(r[1], str), r[1]
+        assert r[3] == comm
+        assert r[4] == (0 if comm == "peer" else 1)        # device form vs host-driven form
+    w = _oracle.wish_from_coords(_oracle.random_walk(n))
+    one = bb.StructureSolver(n_iter=3, dtype=dtype, kind="wish", init="spectral", seed=0,
+                             distributed=False).fit(w)
+    scale = numpy.abs(one.structure_).max()
+    for rank, X, hist, _, _ in results:
+        assert numpy.abs(X - one.structure_).max() < tol * scale
+        # exact recovery on a complete map: the stress is at rounding level on both sides
+        assert hist[0] < 1e-6 * (w ** 2).sum() and one.stress_[0] < 1e-6 * (w ** 2).sum()
+    for r in results[1:]:
+        assert numpy.array_equal(results[0][1], r[1])
