@@ -640,3 +640,50 @@ def test_fit_with_spectral_start_across_processes(dtype, tol, world, comm):
         assert hist[0] < 1e-6 * (w ** 2).sum() and one.stress_[0] < 1e-6 * (w ** 2).sum()
     for r in results[1:]:
         assert numpy.array_equal(results[0][1], r[1])
+
+
+def _worker_fit_many(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import blueberry_amd as bb
+        from tests import _oracle
+        sizes = [900, 300, 1500, 640, 1100]
+        mats = [_oracle.wish_from_coords(_oracle.random_walk(n, seed=50 + m)) for m, n in enumerate(sizes)]
+        s = bb.StructureSolver(n_iter=5, dtype="float32", kind="wish", device=0, seed=1).fit_many(mats)
+        q.put((rank, s.structures_, s.stresses_, s.ranks_of_maps_))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, traceback.format_exc(), None, None))
+
+
+def test_fit_many_across_processes(oracle):
+    """Several ranks: the maps are dealt to the ranks, every rank solves its own in one solver on
+    the device, all ranks get all results; each map against the oracle's solve of it (fp32)."""
+    import torch.multiprocessing as mp
+    from tests import _oracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fit_many, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert not isinstance(r[1], str), r[1]
+    assert results[0][3] == results[1][3] and set(results[0][3]) == {0, 1}
+    sizes = [900, 300, 1500, 640, 1100]
+    for m, n in enumerate(sizes):
+        w = _oracle.wish_from_coords(_oracle.random_walk(n, seed=50 + m))
+        x0 = numpy.random.default_rng(1).standard_normal((n, 3))
+        X, h = oracle.solve(w, x0, 5, 1.0 / (2 * n), f64=False)
+        for r in results:
+            assert numpy.abs(r[1][m] - X).max() < 1e-5 * numpy.abs(X).max()
+            assert numpy.abs(r[2][m] / h - 1).max() < 1e-5
+        assert numpy.array_equal(results[0][1][m], results[1][1][m])
