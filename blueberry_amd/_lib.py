@@ -70,6 +70,7 @@ SIGNATURES = {
     "bb_solver_peer_status": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "bb_solver_peer_set_timeout": (c_int, [c_void_p, c_i64]),
     "bb_solver_peer_form": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "bb_solver_peer_set_form": (c_int, [c_void_p, c_int]),
     "bb_solver_comm_world": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "bb_solver_comm_abort": (c_int, [c_void_p]),
     "bb_comm_cached": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_int)]),

@@ -1868,6 +1868,18 @@ int bb_solver_peer_set_timeout(bb_solver *s, int64_t milliseconds) {
     return BB_OK;
 }
 
+int bb_solver_peer_set_form(bb_solver *s, int one_launch) {
+    BB_REQUIRE(s != nullptr, "bb_solver_peer_set_form: solver is NULL");
+    if (!s->peer_connected)
+        return bb::fail(BB_ERR_STATE, "bb_solver_peer_set_form: not connected");
+    // the one-launch form reads "empty" in every slot word it has not been sent: it can only
+    // be chosen while no exchange has run (the two-launch form leaves its partials in the slots)
+    if (s->peer_seq != 0)
+        return bb::fail(BB_ERR_STATE, "bb_solver_peer_set_form: exchanges have already run");
+    s->peer_fused = one_launch != 0;
+    return BB_OK;
+}
+
 int bb_solver_peer_form(bb_solver *s, int *one_launch) {
     BB_REQUIRE(s != nullptr && one_launch != nullptr, "bb_solver_peer_form: NULL argument");
     if (!s->peer_connected) return bb::fail(BB_ERR_STATE, "bb_solver_peer_form: not connected");

@@ -378,6 +378,11 @@ class HipEngine(object):
         _lib.check(self._lib.bb_solver_peer_form(self._h, one), "bb_solver_peer_form")
         return "one launch" if one.value else "two launches"
 
+    def peer_set_form(self, one_launch):
+        """Choose the exchange's form before its first use (the same on every rank)."""
+        _lib.check(self._lib.bb_solver_peer_set_form(self._h, 1 if one_launch else 0),
+                   "bb_solver_peer_set_form")
+
     def peer_set_timeout(self, milliseconds):
         _lib.check(self._lib.bb_solver_peer_set_timeout(self._h, int(milliseconds)),
                    "bb_solver_peer_set_timeout")
@@ -1194,6 +1199,12 @@ def select_exchange(eng, lr, trial=False):
         if not eng.peer_setup():
             raise RuntimeError("BB_COMM=peer but the peer exchange could not be set up: %s"
                                % eng._peer_error)
+        # No trial has compared this exchange with RCCL: keep the two-launch form, which
+        # applies a step whole or not at all and whose flags are ordered by release / acquire.
+        # The one-launch form (data as its own flag, no fences) is taken where a trial has
+        # validated it against RCCL on this very job (below), or on request (BB_PEER_FUSED=1).
+        if not trial and os.environ.get("BB_PEER_FUSED") is None and hasattr(eng, "peer_set_form"):
+            eng.peer_set_form(False)
         state = "peer"
     elif want == "torch":
         state = "torch"

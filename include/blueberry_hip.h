@@ -302,6 +302,13 @@ BB_API int bb_solver_iterate_peer(bb_solver *s, int64_t iters, double lr);
 BB_API int bb_solver_peer_status(bb_solver *s, int *status);
 BB_API int bb_solver_peer_set_timeout(bb_solver *s, int64_t milliseconds);
 BB_API int bb_solver_peer_form(bb_solver *s, int *one_launch);
+/* Choose the form after bb_solver_peer_connect and before the first exchange (identically on
+ * every rank): 0 = the two launches, 1 = the one launch.  The one-launch form rests on
+ * properties of remote stores over xGMI that no one-GPU test can exercise; the Python host
+ * therefore keeps the two-launch form for a fit() that was not preceded by a trial against
+ * RCCL (BB_COMM=peer without BB_COMM_TRIAL / BB_PEER_FUSED), and takes the one-launch form
+ * where a trial has compared its coordinates with RCCL's (bench.py). */
+BB_API int bb_solver_peer_set_form(bb_solver *s, int one_launch);
 
 /* Host-staged access to the exchange buffer, widened to float64, for callers
  * whose collective runs on host memory (MPI, gloo): read after bb_solver_grad,
