@@ -104,6 +104,42 @@ int main(void) {
         printf("resident ContactMap -> solver: stress %.12e (expect %.12e)\n", h1[0], want);
         if (fabs(h1[0] - want) > 1e-12 * want) return 8;
     }
+    /* Several maps in ONE solver (bb_solver_set_maps): two maps of 3 and 2 bins laid end to
+     * end, the second starting at bin 128 (a multiple of the fp64 tile edge of a small
+     * problem), each with its own step and its own stress; checked against the closed form
+     * of each map's stress at the start. */
+    {
+        enum { TOTAL = 130 };
+        const int32_t ti[2] = {0, 1}, tj[2] = {0, 1};         /* the maps' own diagonal tiles */
+        const int64_t begin[3] = {0, 128, TOTAL};
+        const double lrs[2] = {1.0 / 6.0, 1.0 / 4.0};          /* 1 / (2 n_m) */
+        const double wa[9] = {0, 3, 4, 3, 0, 5, 4, 5, 0};      /* a 3-4-5 triangle */
+        const double wb[4] = {0, 2, 2, 0};                     /* two points, 2 apart */
+        static double xm[3 * TOTAL];
+        double per[2], hm[2 * 3];
+        for (int i = 0; i < 3 * TOTAL; i++) xm[i] = 0.0;
+        xm[0] = 0; xm[3] = 1; xm[6] = 0; xm[7] = 1;            /* map 0: (0,0,0) (1,0,0) (0,1,0) */
+        xm[3 * 128] = 0; xm[3 * 129] = 1;                      /* map 1: (0,0,0) (1,0,0) */
+        CHECK(bb_solver_create(&sol, TOTAL, BB_F64, 0, 0, 1, ti, tj, 2));
+        CHECK(bb_solver_set_maps(sol, 2, begin, lrs));
+        CHECK(bb_solver_set_wish_dense_block(sol, wa, 3, 3, 0, BB_KIND_WISH, 3.0));
+        CHECK(bb_solver_set_wish_dense_block(sol, wb, 2, 2, 128, BB_KIND_WISH, 3.0));
+        CHECK(bb_solver_set_coords(sol, xm));
+        CHECK(bb_solver_stress_maps(sol, per, 2));
+        /* map 0: (1-3)^2 + (1-4)^2 + (sqrt 2 - 5)^2; map 1: (1-2)^2 */
+        const double wantA = 4.0 + 9.0 + (sqrt(2.0) - 5.0) * (sqrt(2.0) - 5.0), wantB = 1.0;
+        printf("two maps in one solver: stress %.12f / %.12f (expect %.12f / %.12f)\n", per[0], per[1],
+               wantA, wantB);
+        if (fabs(per[0] - wantA) > 1e-12 * wantA || fabs(per[1] - wantB) > 1e-12) return 9;
+        CHECK(bb_solver_iterate(sol, 3, 1.0));                 /* lr = 1: the maps' own steps */
+        CHECK(bb_solver_get_stress_history(sol, hm, 6, &n_hist));
+        CHECK(bb_solver_get_coords(sol, xm));
+        CHECK(bb_solver_destroy(sol));
+        if (n_hist != 6 || !(hm[2] < hm[0]) || !(hm[3] < hm[1]) || !(hm[4] < hm[2])) return 10;
+        /* two points under the SMACOF step reach their wish distance in one step */
+        if (fabs(fabs(xm[3 * 129] - xm[3 * 128]) - 2.0) > 1e-12 || fabs(hm[3]) > 1e-20) return 11;
+        if (xm[3 * 64] != 0.0) return 12;                      /* padding between the maps */
+    }
     free(xs); free(x0); free(w);
     puts("C-ABI OK");
     return 0;
