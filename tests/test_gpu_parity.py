@@ -1425,6 +1425,48 @@ def test_several_maps_engine_level_properties():
     e.close()
 
 
+def test_round4_entry_points_reject_bad_arguments():
+    """Argument and call-sequence errors of the entry points added in round 4 come back as
+    status codes with a message (ValueError / RuntimeError in Python), never as a fault."""
+    import ctypes
+    lib = _lib.load()
+    e = HipEngine(1600, "float32", tiles=(numpy.array([0, 1, 2, 3], dtype=numpy.int32),
+                                           numpy.array([0, 1, 2, 3], dtype=numpy.int32)))
+    with pytest.raises(ValueError, match="multiple of the tile edge"):
+        e.set_maps([0, 500, 1600], [1.0, 1.0])
+    with pytest.raises(ValueError, match="from 0 to n_bins"):
+        e.set_maps([0, 512, 1500], [1.0, 1.0])
+    with pytest.raises(ValueError):
+        e.set_maps([0, 512, 1600], [1.0])                       # one scale per map
+    e.set_maps([0, 512, 1600], [1.0, 1.0])
+    with pytest.raises(ValueError, match="does not fit"):
+        e.set_wish_dense_block(numpy.ones((1200, 1200)), 512, "wish", 3.0)
+    with pytest.raises(ValueError, match="multiple of the tile edge"):
+        e.set_wish_dense_block(numpy.ones((100, 100)), 100, "wish", 3.0)
+    with pytest.raises(RuntimeError, match="several maps"):
+        e.spectral_init_device(3, numpy.ones((1600, 3)))
+    with pytest.raises(ValueError):
+        _lib.check(lib.bb_solver_stress_maps(e._h, None, 2), "bb_solver_stress_maps")
+    with pytest.raises(RuntimeError, match="not connected"):
+        e.peer_set_form(False)
+    e.close()
+    # resident triples
+    h = _lib.c_void_p()
+    t = numpy.zeros((4, 3))
+    assert lib.bb_triples_create(h, _lib.as_f64_ptr(t), 4, 0, 1, 0) == _lib.BB_ERR_INVALID    # resolution
+    assert lib.bb_triples_create(h, None, 4, 1000, 1, 0) == _lib.BB_ERR_INVALID
+    assert lib.bb_triples_create(h, _lib.as_f64_ptr(t), 4, 1000, 1, 99) == _lib.BB_ERR_INVALID  # device
+    assert lib.bb_triples_create(h, _lib.as_f64_ptr(t), 4, 1000, 1, 0) == _lib.BB_OK
+    present = numpy.zeros(4, dtype=numpy.uint8)
+    assert lib.bb_triples_tiles(h, 700, _lib.BB_F32, present.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)),
+                                5) == _lib.BB_ERR_INVALID                                     # n_blocks is 2
+    assert lib.bb_triples_destroy(h) == _lib.BB_OK and lib.bb_triples_destroy(None) == _lib.BB_OK
+    gen, have = ctypes.c_uint64(7), ctypes.c_int(7)
+    assert lib.bb_comm_cached_generation(0, 0, 2, ctypes.byref(have), ctypes.byref(gen)) == _lib.BB_OK
+    assert have.value == 0 and gen.value == 0                 # nothing cached in this process
+    assert lib.bb_cm_release_scratch(0) == _lib.BB_OK          # nothing to free is fine
+
+
 # ---- API state behaviour -----------------------------------------------------------------
 def test_solver_state_machine():
     n = 300
