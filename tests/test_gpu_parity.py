@@ -1443,6 +1443,7 @@ def test_round4_entry_points_reject_bad_arguments():
         e.set_wish_dense_block(numpy.ones((1200, 1200)), 512, "wish", 3.0)
     with pytest.raises(ValueError, match="multiple of the tile edge"):
         e.set_wish_dense_block(numpy.ones((100, 100)), 100, "wish", 3.0)
+    e.set_wish_dense_block(numpy.ones((512, 512)), 0, "wish", 3.0)
     with pytest.raises(RuntimeError, match="several maps"):
         e.spectral_init_device(3, numpy.ones((1600, 3)))
     with pytest.raises(ValueError):
