@@ -1446,8 +1446,12 @@ def test_round4_entry_points_reject_bad_arguments():
     e.set_wish_dense_block(numpy.ones((512, 512)), 0, "wish", 3.0)
     with pytest.raises(RuntimeError, match="several maps"):
         e.spectral_init_device(3, numpy.ones((1600, 3)))
+    with pytest.raises(RuntimeError, match="no coordinates"):
+        e.stress_maps()
+    e.set_coords(numpy.random.default_rng(0).standard_normal((1600, 3)))
     with pytest.raises(ValueError):
         _lib.check(lib.bb_solver_stress_maps(e._h, None, 2), "bb_solver_stress_maps")
+    assert e.stress_maps().shape == (2,)
     with pytest.raises(RuntimeError, match="not connected"):
         e.peer_set_form(False)
     e.close()
