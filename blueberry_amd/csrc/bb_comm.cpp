@@ -2,6 +2,7 @@
 #include "bb_comm.h"
 
 #include <dlfcn.h>
+#include <stdlib.h>
 
 #include <mutex>
 
@@ -11,6 +12,10 @@ const Rccl &rccl() {
     static Rccl table;
     static std::once_flag once;
     std::call_once(once, [] {
+        // BB_NO_RCCL=1: behave as if librccl could not be loaded (a rehearsal of the paths
+        // that run without the library's communicator: torch.distributed as the reference
+        // of the exchange trial, and as the transport)
+        if (const char *e = getenv("BB_NO_RCCL")) if (atoi(e) != 0) return;
         // RTLD_NOLOAD first: reuse the image the process already has (torch's)
         void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);

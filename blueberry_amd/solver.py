@@ -1213,7 +1213,20 @@ def select_exchange(eng, lr, trial=False):
     else:
         have_rccl = _comm_get(eng)
         have_peer = eng.peer_setup()
-        if have_rccl and have_peer:
+        # what the peer exchange is held against, and what runs if it loses: the library's
+        # communicator, or -- when that could not be made -- torch.distributed's all-reduce on
+        # the exchange buffer (round 3 gave the peer exchange up with it: no RCCL, no trial)
+        ref = "rccl" if have_rccl else "torch"
+
+        def torch_step(k, step_lr):
+            t = eng.exchange_tensor()
+            for _ in range(k):
+                eng.grad()
+                allreduce_exchange(t)
+                eng.apply(step_lr)
+
+        ref_step = eng.iterate_dist if have_rccl else torch_step
+        if have_peer and (have_rccl or hasattr(eng, "exchange_tensor")):
             x0 = eng.get_coords()
             set_limit = getattr(eng, "peer_set_timeout", None)
             if set_limit:
@@ -1231,20 +1244,21 @@ def select_exchange(eng, lr, trial=False):
                         eng._comm_trial_error = "%s; abort: %s" % (
                             getattr(eng, "_comm_trial_error", None), exc)
 
-            for name, step in (("rccl", eng.iterate_dist), ("peer", eng.iterate_peer)):
+            for name, step in ((ref, ref_step), ("peer", eng.iterate_peer)):
                 runs[name] = _trial_leg(eng, name, step, lr, x0, 30)
                 abort_if_failed(name)
+            runs["rccl"] = runs[ref]            # (the reference leg, whichever transport it is)
             if runs["rccl"][0] and runs["peer"][0]:
                 # the leg that runs first is timed on a chip whose clocks have not settled
                 # (a block right after idle runs 4-19 % slow): RCCL gets a
                 # second timing behind the peer leg and keeps its better one.  (Leg outcomes
                 # are agreed between the ranks, so every rank takes this branch or none.)
-                again = _trial_leg(eng, "rccl", eng.iterate_dist, lr, x0, 30)
+                again = _trial_leg(eng, ref, ref_step, lr, x0, 30)
                 if again[0]:
                     runs["rccl"] = (True, runs["rccl"][1], min(runs["rccl"][2], again[2]))
                 else:
-                    runs["rccl"] = (False, None, float("inf"))
-                    abort_if_failed("rccl")
+                    runs["rccl"] = runs[ref] = (False, None, float("inf"))
+                    abort_if_failed(ref)
             if set_limit and runs["peer"][0]:
                 set_limit(int(os.environ.get("BB_PEER_TIMEOUT_MS", "10000")))
             eng.set_coords(x0)
@@ -1266,13 +1280,14 @@ def select_exchange(eng, lr, trial=False):
             # more than the trial's own noise (3 %), not by a coin flip
             use_peer = all(e[0] for e in every) and t_peer < 0.97 * t_rccl
             ms = lambda t: t * 1e3 if numpy.isfinite(t) else None
-            eng._comm_trial = {"agree": all(e[0] for e in every), "rccl_ms": ms(t_rccl),
+            eng._comm_trial = {"agree": all(e[0] for e in every), "reference": ref,
+                               "rccl_ms": ms(t_rccl),      # (the reference leg's time)
                                "peer_ms": ms(t_peer),
                                "error": getattr(eng, "_comm_trial_error", None)}
             if use_peer:
                 state = "peer"
             elif runs["rccl"][0]:
-                state = "rccl"
+                state = ref
             else:
                 state = "torch"
         elif have_rccl:

@@ -270,6 +270,24 @@ class _ScriptedEngine(object):
         self.calls.append("peer")
 
 
+class _ScriptedTorchEngine(_ScriptedEngine):
+    """The same with the torch.distributed path played too (exchange_tensor / grad / apply):
+    what the trial holds the peer exchange against when the library's communicator cannot
+    be made."""
+
+    def exchange_tensor(self):
+        import torch
+        return torch.zeros(3)
+
+    def grad(self):
+        import time
+        time.sleep(self.rccl_sleep)
+
+    def apply(self, lr):
+        self.x = self.x - lr
+        self.calls.append("torch")
+
+
 @pytest.fixture
 def one_rank_group(monkeypatch):
     import torch.distributed as dist
@@ -306,6 +324,25 @@ def test_select_exchange_auto_is_a_measured_validated_choice(one_rank_group, mon
         agree = not kwargs.get("peer_shift") and not kwargs.get("peer_raises")
         assert e._comm_trial["agree"] == agree
     assert solver.select_exchange(e, 0.5) == expect            # decided once
+
+
+@pytest.mark.parametrize("kwargs,expect", [
+    (dict(rccl_ok=False, peer_sleep=0.0, rccl_sleep=0.002), "peer"),     # agrees with torch, faster
+    (dict(rccl_ok=False, peer_shift=0.1, rccl_sleep=0.002), "torch"),    # faster but WRONG
+    (dict(rccl_ok=False, peer_sleep=0.002, rccl_sleep=0.0), "torch"),    # agrees but slower
+])
+def test_trial_against_torch_when_the_library_communicator_cannot_be_made(one_rank_group,
+                                                                           monkeypatch, kwargs, expect):
+    """Round 3 gave the peer exchange up together with the library's RCCL communicator: without
+    it there was no trial.  Now the peer exchange is held against torch.distributed's
+    all-reduce instead, and the loser of THAT comparison is what runs."""
+    from blueberry_amd import solver
+    monkeypatch.setattr(one_rank_group, "get_backend", lambda *a, **k: "nccl")
+    e = _ScriptedTorchEngine(**kwargs)
+    x0 = e.get_coords()
+    assert solver.select_exchange(e, 0.5, trial=True) == expect
+    assert e._comm_trial["reference"] == "torch" and "torch" in e.calls and "rccl" not in e.calls
+    assert numpy.array_equal(e.get_coords(), x0)               # the start was restored
 
 
 def test_select_exchange_without_trial_is_rccl(one_rank_group, monkeypatch):
