@@ -2361,15 +2361,16 @@ template <typename T>
 int spectral_init_t(bb_solver *s, int n_iter, const double *v0) {
     const int64_t n = s->L.n_bins, n_pad = s->L.n_pad, n3 = n_pad * 3;
     if (!s->d_mv_in) BB_TRY(dev_alloc((char **)&s->d_mv_in, n3 * (int64_t)sizeof(T)));
-    // V, Z: (n_pad,3) doubles; dS: 12 sums (the two host steps at the end); dP: per-workgroup
-    // partial sums of a pass; dA: the 3 x 3 maps the passes hand to one another; dF: rank-loss flag
-    bb::DevBuf bV, bZ, bS, bP, bA, bF;
+    // V, Z: (n_pad,3) doubles; dS: 12 sums (the two host steps at the end); dP0 / dP1: the
+    // per-workgroup partial sums a pass leaves for the next one (two buffers: a pass reads its
+    // producer's while it writes its own); dF: rank-loss flag
+    bb::DevBuf bV, bZ, bS, bP, bF;
     if (bV.alloc((size_t)n3 * 8) != hipSuccess || bZ.alloc((size_t)n3 * 8) != hipSuccess ||
-        bS.alloc(12 * 8) != hipSuccess || bP.alloc((size_t)kSpMaxGroups * 12 * 8) != hipSuccess ||
-        bA.alloc(4 * sizeof(Affine3)) != hipSuccess || bF.alloc(sizeof(int)) != hipSuccess)
+        bS.alloc(12 * 8) != hipSuccess || bP.alloc((size_t)2 * kSpMaxGroups * 12 * 8) != hipSuccess ||
+        bF.alloc(sizeof(int)) != hipSuccess)
         return bb::fail(BB_ERR_NOMEM, "bb_solver_spectral_init: out of device memory");
-    double *dV = (double *)bV.p, *dZ = (double *)bZ.p, *dS = (double *)bS.p, *dP = (double *)bP.p;
-    Affine3 *dA = (Affine3 *)bA.p;
+    double *dV = (double *)bV.p, *dZ = (double *)bZ.p, *dS = (double *)bS.p;
+    double *dP0 = (double *)bP.p, *dP1 = dP0 + kSpMaxGroups * 12;
     int *dF = (int *)bF.p;
     hipStream_t st = s->stream;
     const dim3 gvec((unsigned)((n_pad + kSpWG - 1) / kSpWG)), bwg(kSpWG);
@@ -2382,39 +2383,31 @@ int spectral_init_t(bb_solver *s, int n_iter, const double *v0) {
         BB_HIP_CHECK(hipMemcpy(sums, dS, sizeof(sums), hipMemcpyDeviceToHost));
         return BB_OK;
     };
-    auto finalize = [&](int mode, double scale, Affine3 *out) -> int {
-        BB_HIP_CHECK(bb::launch(sp_finalize_kernel, dim3(1), dim3(768), 0, st, (const double *)dP,
-                                groups, n, mode, scale, out, dF));
-        return BB_OK;
-    };
-    // dZ (any basis of the subspace, its 12 sums in dP) -> dV orthonormal by Cholesky-QR, twice
+    // dZ (any basis of the subspace, its 12 sums in dP1) -> dV orthonormal by Cholesky-QR, twice
     // (the second pass removes what the first leaves at cond(Z)^2 * eps), and the sweep's
-    // right-hand sides d_mv_in = (T)(V - mean V): three kernels + two 3 x 3 steps, no host
+    // right-hand sides d_mv_in = (T)(V - mean V): two kernels, the 3 x 3 steps in their prologues
     auto orthonormalise = [&]() -> int {
-        BB_TRY(finalize(kSpChol, 1.0, dA + 1));
         BB_HIP_CHECK(bb::launch(sp_affine_stats_kernel<double>, ggrp, bwg, 0, st, (const double *)dZ, dV,
-                                n, n_pad, (const Affine3 *)(dA + 1), dP));
-        BB_TRY(finalize(kSpCholMean, 1.0, dA + 2));
+                                n, n_pad, (const double *)dP1, groups, (int)kSpChol, 1.0, dF, dP0));
         BB_HIP_CHECK(bb::launch(sp_affine_centre_kernel<T>, gvec, bwg, 0, st, (const double *)dV, dV,
-                                (T *)s->d_mv_in, n, n_pad, (const Affine3 *)(dA + 2)));
+                                (T *)s->d_mv_in, n, n_pad, (const double *)dP0, groups, dF));
         return BB_OK;
     };
     // dZ = -1/2 J (D o D) J V  (J = I - 11'/n) from the centred V in d_mv_in: sweep, sum over
-    // the ranks, centre; the 12 sums of dZ are left in dP
+    // the ranks, centre; the 12 sums of dZ are left in dP1
     auto apply_B = [&]() -> int {
         BB_TRY(launch_grad(s, kOpMatvec2, s->d_mv_in));
         BB_TRY(exchange_sum(s));
-        BB_HIP_CHECK(bb::launch(sp_stats_kernel<T>, ggrp, bwg, 0, st, (const T *)s->d_exch, n, n_pad, dP));
-        BB_TRY(finalize(kSpMean, -0.5, dA));
+        BB_HIP_CHECK(bb::launch(sp_stats_kernel<T>, ggrp, bwg, 0, st, (const T *)s->d_exch, n, n_pad, dP0));
         BB_HIP_CHECK(bb::launch(sp_affine_stats_kernel<T>, ggrp, bwg, 0, st, (const T *)s->d_exch, dZ, n,
-                                n_pad, (const Affine3 *)dA, dP));
+                                n_pad, (const double *)dP0, groups, (int)kSpMean, -0.5, dF, dP1));
         return BB_OK;
     };
     BB_HIP_CHECK(hipMemsetAsync(dF, 0, sizeof(int), st));
     BB_HIP_CHECK(hipMemsetAsync(s->d_V, 0, (size_t)n3 * sizeof(T), st));   // exchange_sum reads it
     BB_HIP_CHECK(hipMemsetAsync(dZ, 0, (size_t)n3 * 8, st));
     BB_HIP_CHECK(hipMemcpyAsync(dZ, v0, (size_t)n * 24, hipMemcpyHostToDevice, st));
-    BB_HIP_CHECK(bb::launch(sp_stats_kernel<double>, ggrp, bwg, 0, st, (const double *)dZ, n, n_pad, dP));
+    BB_HIP_CHECK(bb::launch(sp_stats_kernel<double>, ggrp, bwg, 0, st, (const double *)dZ, n, n_pad, dP1));
     BB_TRY(orthonormalise());
     for (int it = 0; it < n_iter; ++it) {
         BB_TRY(apply_B());

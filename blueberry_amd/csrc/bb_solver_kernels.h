@@ -2299,12 +2299,11 @@ __global__ __launch_bounds__(256) void affine3_kernel(const TI *__restrict__ in,
 // bb_solver_spectral_init used to read 12 sums back four times per product (centre, centre,
 // two Cholesky-QR passes): four stream synchronisations around a sweep that takes 0.1 ms on a
 // 1/8 share.  Now the 3 x 3 work stays on the device: every pass over an (n,3) array is ONE
-// kernel that applies the affine map the previous step left in device memory and leaves the
-// 12 sums of its OUTPUT (Gram matrix + column sums) as per-workgroup partials; a one-workgroup
-// kernel adds them in a fixed order, does the 3 x 3 step (mean, or Cholesky factor and its
-// inverse) and writes the next map.  A factor that is not positive definite (the iterate lost
-// rank) raises a flag the host reads once, at the end.  Sums are in double, fixed order:
-// bitwise reproducible, and identical on every rank of a multi-rank start.
+// kernel that leaves the 12 sums of its OUTPUT (Gram matrix + column sums) as per-workgroup
+// partials, and the NEXT pass adds them in a fixed order and does the 3 x 3 step (mean, or
+// Cholesky factor and its inverse) in its own prologue.  A factor that is not positive definite
+// (the iterate lost rank) raises a flag the host reads once, at the end.  Sums are in double,
+// fixed order: bitwise reproducible, and identical on every rank of a multi-rank start.
 constexpr int kSpWG = 256;          // threads per workgroup of the passes
 constexpr int kSpMaxGroups = 256;   // partials per pass
 
@@ -2354,57 +2353,6 @@ __global__ __launch_bounds__(kSpWG) void sp_stats_kernel(const TI *__restrict__ 
     sp_store_partial(acc, partial);
 }
 
-// out_i = a->scale * ((in_i - a->mean) a->m) for rows < n_bins (0 beyond), the map read from
-// device memory, + the partial sums of the OUTPUT.  In place (in == out) is fine: a thread
-// reads its row before it writes it.
-template <typename TI>
-__global__ __launch_bounds__(kSpWG) void sp_affine_stats_kernel(const TI *in, double *out,
-                                                                int64_t n_bins, int64_t n_pad,
-                                                                const Affine3 *__restrict__ a,
-                                                                double *__restrict__ partial) {
-    int64_t r0, r1;
-    sp_rows(n_pad, r0, r1);
-    const Affine3 A = *a;
-    double acc[12];
-#pragma unroll
-    for (int q = 0; q < 12; ++q) acc[q] = 0.0;
-    for (int64_t i = r0 + threadIdx.x; i < r1; i += kSpWG) {
-        double o0 = 0.0, o1 = 0.0, o2 = 0.0;
-        if (i < n_bins) {
-            const double x0 = (double)in[3 * i] - A.mean[0], x1 = (double)in[3 * i + 1] - A.mean[1],
-                         x2 = (double)in[3 * i + 2] - A.mean[2];
-            o0 = A.scale * (x0 * A.m[0] + x1 * A.m[3] + x2 * A.m[6]);
-            o1 = A.scale * (x0 * A.m[1] + x1 * A.m[4] + x2 * A.m[7]);
-            o2 = A.scale * (x0 * A.m[2] + x1 * A.m[5] + x2 * A.m[8]);
-            sp_accumulate(acc, o0, o1, o2);
-        }
-        out[3 * i] = o0; out[3 * i + 1] = o1; out[3 * i + 2] = o2;
-    }
-    sp_store_partial(acc, partial);
-}
-
-// The last pass of an orthonormalisation: V = V' a[0].m, written as double, and the sweep's
-// right-hand sides mv = (T)(V - a[1].mean) -- V centred, in the solver's type -- in one go.
-template <typename T>
-__global__ __launch_bounds__(kSpWG) void sp_affine_centre_kernel(const double *in, double *out_v,
-                                                                 T *__restrict__ out_mv,
-                                                                 int64_t n_bins, int64_t n_pad,
-                                                                 const Affine3 *__restrict__ a) {
-    const int64_t i = (int64_t)blockIdx.x * kSpWG + threadIdx.x;
-    if (i >= n_pad) return;
-    double o0 = 0.0, o1 = 0.0, o2 = 0.0, c0 = 0.0, c1 = 0.0, c2 = 0.0;
-    if (i < n_bins) {
-        const Affine3 A = a[0];
-        const double x0 = in[3 * i], x1 = in[3 * i + 1], x2 = in[3 * i + 2];
-        o0 = x0 * A.m[0] + x1 * A.m[3] + x2 * A.m[6];
-        o1 = x0 * A.m[1] + x1 * A.m[4] + x2 * A.m[7];
-        o2 = x0 * A.m[2] + x1 * A.m[5] + x2 * A.m[8];
-        c0 = o0 - a[1].mean[0]; c1 = o1 - a[1].mean[1]; c2 = o2 - a[1].mean[2];
-    }
-    out_v[3 * i] = o0; out_v[3 * i + 1] = o1; out_v[3 * i + 2] = o2;
-    out_mv[3 * i] = (T)c0; out_mv[3 * i + 1] = (T)c1; out_mv[3 * i + 2] = (T)c2;
-}
-
 // g = R^T R (R upper) -> R^-1 (upper), 3 x 3 row-major.  False if g is not positive definite.
 __host__ __device__ inline bool sp_chol3_inv_upper(const double *g, double *rinv) {
     double r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -2431,55 +2379,119 @@ __host__ __device__ inline bool sp_chol3_inv_upper(const double *g, double *rinv
     return true;
 }
 
-// One workgroup of 12 waves: wave q adds value q of the `groups` partials (lane l takes the
-// groups l, l + 64, ... in order, then a fixed shuffle tree), thread 0 does the 3 x 3 step.
-//   kSpMean     out[0] = { mean = column sums / n, M = I, scale }           (centring)
-//   kSpChol     out[0] = { 0, R^-1, 1 } with R^T R = the Gram matrix        (Cholesky-QR pass)
-//   kSpCholMean the same, and out[1].mean = (column sums / n) R^-1: the mean of what the
-//               map is about to produce (sp_affine_centre_kernel)
+// The 3 x 3 step BETWEEN two passes, done by every workgroup of the consuming pass for itself
+// (round 4, second version: as a kernel of its own it cost what every tiny kernel costs here,
+// 4.7 us by the kernel trace, three times per product).  The producer left `groups` partial
+// sums of 12 values; 12 x 16 threads add them in a fixed order (thread (q, l) takes the groups
+// l, l + 16, ... of value q, then a 16-lane tree), thread 0 does the 3 x 3 step, LDS hands the
+// map to everybody.  Every workgroup -- and every rank -- computes the same bits.
+//   kSpMean     A = { mean = column sums / n, M = I, scale }           (centring)
+//   kSpChol     A = { 0, R^-1, 1 } with R^T R = the Gram matrix        (Cholesky-QR pass)
+//   kSpCholMean the same, and B.mean = (column sums / n) R^-1: the mean of what the map is
+//               about to produce (sp_affine_centre_kernel)
 // A Gram matrix that is not positive definite sets *flag and leaves the identity.
 enum { kSpMean = 0, kSpChol = 1, kSpCholMean = 2 };
-__global__ __launch_bounds__(768) void sp_finalize_kernel(const double *__restrict__ partial,
-                                                          int groups, int64_t n_bins, int mode,
-                                                          double scale, Affine3 *__restrict__ out,
-                                                          int *__restrict__ flag) {
+__device__ __forceinline__ void sp_map_from_partials(const double *__restrict__ partial, int groups,
+                                                     int64_t n_bins, int mode, double scale,
+                                                     int *__restrict__ flag, Affine3 &A, Affine3 &B) {
     __shared__ double tot[12];
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    double v = 0.0;
-    for (int g = lane; g < groups; g += 64) v += partial[(int64_t)g * 12 + q];
+    __shared__ Affine3 maps[2];
+    const int t = threadIdx.x;
+    if (t < 192) {
+        const int q = t >> 4, l = t & 15;
+        double v = 0.0;
+        for (int g = l; g < groups; g += 16) v += partial[(int64_t)g * 12 + q];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) tot[q] = v;
+        for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+        if (l == 0) tot[q] = v;
+    }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    Affine3 A;
-    for (int k = 0; k < 3; ++k) A.mean[k] = 0.0;
-    for (int k = 0; k < 9; ++k) A.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
-    A.scale = 1.0;
-    if (mode == kSpMean) {
-        for (int k = 0; k < 3; ++k) A.mean[k] = tot[9 + k] / (double)n_bins;
-        A.scale = scale;
-        out[0] = A;
-        return;
+    if (t == 0) {
+        Affine3 a, b;
+        for (int k = 0; k < 3; ++k) a.mean[k] = 0.0;
+        for (int k = 0; k < 9; ++k) a.m[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        a.scale = 1.0;
+        b = a;
+        if (mode == kSpMean) {
+            for (int k = 0; k < 3; ++k) a.mean[k] = tot[9 + k] / (double)n_bins;
+            a.scale = scale;
+        } else {
+            double rinv[9];
+            if (!sp_chol3_inv_upper(tot, rinv)) {
+                *flag = 1;                       // (every workgroup writes the same 1)
+            } else {
+                for (int k = 0; k < 9; ++k) a.m[k] = rinv[k];
+                b = a;
+                const double m0 = tot[9] / (double)n_bins, m1 = tot[10] / (double)n_bins,
+                             m2 = tot[11] / (double)n_bins;
+                b.mean[0] = m0 * rinv[0] + m1 * rinv[3] + m2 * rinv[6];
+                b.mean[1] = m0 * rinv[1] + m1 * rinv[4] + m2 * rinv[7];
+                b.mean[2] = m0 * rinv[2] + m1 * rinv[5] + m2 * rinv[8];
+            }
+        }
+        maps[0] = a;
+        maps[1] = b;
     }
-    double rinv[9];
-    if (!sp_chol3_inv_upper(tot, rinv)) {
-        *flag = 1;
-        out[0] = A;
-        if (mode == kSpCholMean) out[1] = A;
-        return;
+    __syncthreads();
+    A = maps[0];
+    B = maps[1];
+}
+
+// out_i = A.scale * ((in_i - A.mean) A.m) for rows < n_bins (0 beyond), A = the 3 x 3 step
+// `mode` on the producer's partial sums, + the partial sums of the OUTPUT.  In place
+// (in == out) is fine: a thread reads its row before it writes it.
+template <typename TI>
+__global__ __launch_bounds__(kSpWG) void sp_affine_stats_kernel(const TI *in, double *out,
+                                                                int64_t n_bins, int64_t n_pad,
+                                                                const double *__restrict__ partial_in,
+                                                                int groups, int mode, double scale,
+                                                                int *__restrict__ flag,
+                                                                double *__restrict__ partial) {
+    Affine3 A, unused;
+    sp_map_from_partials(partial_in, groups, n_bins, mode, scale, flag, A, unused);
+    int64_t r0, r1;
+    sp_rows(n_pad, r0, r1);
+    double acc[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) acc[q] = 0.0;
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += kSpWG) {
+        double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+        if (i < n_bins) {
+            const double x0 = (double)in[3 * i] - A.mean[0], x1 = (double)in[3 * i + 1] - A.mean[1],
+                         x2 = (double)in[3 * i + 2] - A.mean[2];
+            o0 = A.scale * (x0 * A.m[0] + x1 * A.m[3] + x2 * A.m[6]);
+            o1 = A.scale * (x0 * A.m[1] + x1 * A.m[4] + x2 * A.m[7]);
+            o2 = A.scale * (x0 * A.m[2] + x1 * A.m[5] + x2 * A.m[8]);
+            sp_accumulate(acc, o0, o1, o2);
+        }
+        out[3 * i] = o0; out[3 * i + 1] = o1; out[3 * i + 2] = o2;
     }
-    for (int k = 0; k < 9; ++k) A.m[k] = rinv[k];
-    out[0] = A;
-    if (mode == kSpCholMean) {
-        Affine3 B = A;
-        const double m0 = tot[9] / (double)n_bins, m1 = tot[10] / (double)n_bins,
-                     m2 = tot[11] / (double)n_bins;
-        B.mean[0] = m0 * rinv[0] + m1 * rinv[3] + m2 * rinv[6];
-        B.mean[1] = m0 * rinv[1] + m1 * rinv[4] + m2 * rinv[7];
-        B.mean[2] = m0 * rinv[2] + m1 * rinv[5] + m2 * rinv[8];
-        out[1] = B;
+    sp_store_partial(acc, partial);
+}
+
+// The last pass of an orthonormalisation: V = V' R^-1, written as double, and the sweep's
+// right-hand sides mv = (T)(V - mean V) -- V centred, in the solver's type -- in one go; R^-1 and
+// the mean from the producer's partial sums (kSpCholMean).
+template <typename T>
+__global__ __launch_bounds__(kSpWG) void sp_affine_centre_kernel(const double *in, double *out_v,
+                                                                 T *__restrict__ out_mv,
+                                                                 int64_t n_bins, int64_t n_pad,
+                                                                 const double *__restrict__ partial_in,
+                                                                 int groups, int *__restrict__ flag) {
+    Affine3 A, B;
+    sp_map_from_partials(partial_in, groups, n_bins, kSpCholMean, 1.0, flag, A, B);
+    const int64_t i = (int64_t)blockIdx.x * kSpWG + threadIdx.x;
+    if (i >= n_pad) return;
+    double o0 = 0.0, o1 = 0.0, o2 = 0.0, c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    if (i < n_bins) {
+        const double x0 = in[3 * i], x1 = in[3 * i + 1], x2 = in[3 * i + 2];
+        o0 = x0 * A.m[0] + x1 * A.m[3] + x2 * A.m[6];
+        o1 = x0 * A.m[1] + x1 * A.m[4] + x2 * A.m[7];
+        o2 = x0 * A.m[2] + x1 * A.m[5] + x2 * A.m[8];
+        c0 = o0 - B.mean[0]; c1 = o1 - B.mean[1]; c2 = o2 - B.mean[2];
     }
+    out_v[3 * i] = o0; out_v[3 * i + 1] = o1; out_v[3 * i + 2] = o2;
+    out_mv[3 * i] = (T)c0; out_mv[3 * i + 1] = (T)c1; out_mv[3 * i + 2] = (T)c2;
 }
 
 template <typename T>
