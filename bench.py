@@ -2,6 +2,7 @@
 """bench.py -- pair-updates/s of the 3D-structure solver on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--bins 50000] [--dtype float32]
+    python bench.py --workload genome10kb [--gpus N] ...      BASELINE config 5 (see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -16,6 +17,12 @@ a dense synthetic N = 50,000-bin wish-distance matrix, fp32, resident in HBM
 N GPUs split the SAME matrix (strong scaling): each rank owns a contiguous
 1/N of the packed units and the ranks exchange one all-reduce of the
 (3*n_pad+2)-element gradient buffer per step (RCCL over xGMI).
+
+--workload genome10kb is BASELINE config 5: the whole hg19 genome at 10 kb bins (N = 309,568)
+as blocked-sparse 512 x 512 tiles -- one block per chromosome + a 10-Mb band, 10,013 of 183,315
+upper tiles, 2.54 G stored pairs (the reference's dense matrix, blueberry/datatypes.pyx:99, would
+be 720 GB) -- with pairs = stored pairs, the roofline on the stored-pair bytes, and the CPU
+baseline on the same block structure at 50 kb.
 
 Order of the measurements: convergence legs, read sweep, --settle-ms of untimed iterations
 (the chip's clocks need load to settle), W warm-up steps, the K timed
