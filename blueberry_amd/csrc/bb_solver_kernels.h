@@ -1993,7 +1993,9 @@ __global__ __launch_bounds__(256) void scatter_entries_kernel(
     double v = src.tr ? nan_to_num_f64(src.tr[k * src.st + 2 * src.sc]) : src.vals[k];
     // KR balancing + observed/expected, the element-wise form of the loop at
     // reference datatypes.pyx:166-169 (same operation order)
-    if (kr != nullptr) v = v / (kr[i] * kr[j] * krexp[j - i]);
+    // (... followed by the reference's nan_to_num over the matrix, pyx:171: a NaN quotient is 0 =
+    // no constraint, an overflowing one the largest double -- as ContactMap.normalize leaves it)
+    if (kr != nullptr) v = nan_to_num_f64(v / (kr[i] * kr[j] * krexp[j - i]));
     const bool ok = (v > 0.0) && (v <= 1.7976931348623157e308);
     if (!ok)
         v = 0.0;

@@ -158,9 +158,10 @@ BB_API int bb_solver_stress_maps(bb_solver *s, double *stress, int n_maps);
  * dense (n_bins+1)^2 host matrix, for genome-wide 10 kb maps (BASELINE config 5).
  * KRnorm / KRexpected (n_bins doubles each, or both NULL): each value is first
  * divided by KRnorm[i] * KRnorm[j] * KRexpected[j - i] (i < j), the element-wise
- * form of ContactMap.normalize (blueberry/datatypes.pyx:166-169); a NaN or
- * non-finite quotient means "no constraint" (the reference's nan_to_num gives
- * 0 for NaN as well). */
+ * form of ContactMap.normalize (blueberry/datatypes.pyx:166-169), followed by the
+ * reference's nan_to_num (pyx:171): a NaN quotient is 0 = "no constraint", an overflowing
+ * one the largest double (whose wish distance, 1.8e-103, is a constraint in fp64 and
+ * below the wish floor in fp32) -- exactly what the dense ContactMap path gives. */
 BB_API int bb_solver_set_wish_sparse(bb_solver *s, const int64_t *rows, const int64_t *cols,
                                      const double *vals, int64_t nnz, int kind, double alpha,
                                      const double *KRnorm, const double *KRexpected);

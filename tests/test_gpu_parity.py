@@ -960,6 +960,17 @@ def test_fit_triples_bins_and_cleans_on_the_device(oracle):
     X_ref, h_ref = oracle.solve(wish, x0, k, lr)
     s = bb.StructureSolver(n_iter=k, lr=lr, dtype="float64").fit_triples(triples, res, n_bins, init=x0)
     assert numpy.abs(s.stress_ / h_ref - 1).max() < 1e-12 and _rel(s.structure_, X_ref) < 1e-12
+    # with KR vectors an infinite count overflows the quotient: the reference's nan_to_num
+    # (pyx:171) makes it the largest double -- a (tiny) wish distance in fp64, not "no
+    # constraint" (found by tools/fit_triples_fuzz.py: round 3 dropped such a pair)
+    kr = 0.5 + numpy.random.default_rng(1).random(n_bins)
+    ke = 20.0 / (1.0 + numpy.arange(n_bins)) + 0.3
+    norm = oracle.contactmap_normalize(oracle.contactmap_scatter(triples, res, n_bins), kr, ke)
+    assert (norm == numpy.finfo(float).max).any()
+    X_ref, h_ref = oracle.solve(oracle.counts_to_wish(norm, 3.0), x0, k, lr)
+    s = bb.StructureSolver(n_iter=k, lr=lr, dtype="float64").fit_triples(triples, res, n_bins, KRnorm=kr,
+                                                                         KRexpected=ke, init=x0)
+    assert numpy.abs(s.stress_ / h_ref - 1).max() < 1e-12 and _rel(s.structure_, X_ref) < 1e-12
     bad = triples.copy()
     bad[7, 1] = (n_bins + 5) * float(res)
     with pytest.raises(ValueError, match="outside"):
