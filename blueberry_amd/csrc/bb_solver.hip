@@ -996,6 +996,8 @@ int bb_solver_set_maps(bb_solver *s, int n_maps, const int64_t *bin_begin, const
     if (idx.empty()) idx.push_back(0);
     hipFree(s->d_blk_scale); hipFree(s->d_map_ptr); hipFree(s->d_map_idx); hipFree(s->d_map_scalar);
     s->d_blk_scale = nullptr; s->d_map_ptr = s->d_map_idx = nullptr; s->d_map_scalar = nullptr;
+    s->n_maps = 1;                 // (what holds if an allocation below fails: one map, no tables)
+    s->map_begin.clear();
     BB_TRY(dev_alloc((char **)&s->d_blk_scale, nb * es));
     BB_TRY(dev_alloc(&s->d_map_ptr, (int64_t)ptr.size()));
     BB_TRY(dev_alloc(&s->d_map_idx, (int64_t)idx.size()));
@@ -1040,6 +1042,7 @@ int bb_solver_set_wish_from_cm_block(bb_solver *s, const bb_cm *cm, int64_t bin_
 #undef BB_PACKB
     }
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    BB_TRY(refresh_full(s));       // (a small one-map solver iterates over the full matrix)
     s->have_wish = true;
     return BB_OK;
 }
@@ -1056,6 +1059,7 @@ int bb_solver_set_wish_dense_block(bb_solver *s, const double *host, int64_t ld,
     BB_REQUIRE(kind == BB_KIND_WISH || alpha > 0.0, "bb_solver_set_wish_dense_block: alpha must be > 0");
     BB_TRY(bb::enter_device(s->device));
     int rc = BB_BY_LAYOUT(s, set_wish_dense_t, s, host, ld, kind, alpha, bin_offset, n_sub);
+    if (rc == BB_OK) rc = refresh_full(s);
     if (rc == BB_OK) s->have_wish = true;
     return rc;
 }

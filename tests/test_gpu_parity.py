@@ -1436,6 +1436,29 @@ def test_several_maps_engine_level_properties():
     e.close()
 
 
+def test_block_setters_on_a_small_one_map_solver_refresh_its_full_matrix():
+    """A one-map solver of at most 4,096 bins iterates over a full (both triangles) copy of
+    the map; the block setters rebuild it as bb_solver_set_wish_dense does (before this test
+    they left it as it was -- silently stale)."""
+    n, k, lr = 900, 4, 1.0 / 1800
+    w = _oracle.wish_from_coords(_oracle.random_walk(n, seed=2))
+    x0 = _oracle.noisy_init(_oracle.random_walk(n, seed=2), seed=3)
+    ref = HipEngine(n, "float64")
+    assert ref.iteration_path()[0] == "row_owner"
+    ref.set_wish_dense(w, "wish", 3.0)
+    ref.set_coords(x0)
+    ref.iterate(k, lr)
+    e = HipEngine(n, "float64")
+    e.set_wish_dense(numpy.ones((n, n)), "wish", 3.0)          # something else first
+    e.set_wish_dense_block(w, 0, "wish", 3.0)
+    e.set_coords(x0)
+    e.iterate(k, lr)
+    assert numpy.array_equal(e.get_coords(), ref.get_coords())
+    assert numpy.array_equal(e.stress_history(), ref.stress_history())
+    e.close()
+    ref.close()
+
+
 def test_round4_entry_points_reject_bad_arguments():
     """Argument and call-sequence errors of the entry points added in round 4 come back as
     status codes with a message (ValueError / RuntimeError in Python), never as a fault."""
