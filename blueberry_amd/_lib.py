@@ -87,6 +87,7 @@ SIGNATURES = {
     "bb_solver_write_exchange": (c_int, [c_void_p, p_dbl, c_i64]),
     "bb_solver_matvec_sq": (c_int, [c_void_p, p_dbl, p_dbl]),
     "bb_solver_spectral_init": (c_int, [c_void_p, c_int, p_dbl]),
+    "bb_solver_spectral_init_tol": (c_int, [c_void_p, c_int, c_dbl, p_dbl, ctypes.POINTER(c_int), p_dbl]),
     "bb_solver_stress": (c_int, [c_void_p, p_dbl]),
     "bb_solver_get_stress_history": (c_int, [c_void_p, p_dbl, c_i64, p_i64]),
     "bb_solver_sync": (c_int, [c_void_p]),

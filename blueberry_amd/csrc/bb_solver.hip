@@ -2362,7 +2362,8 @@ void jacobi3(double *a, double *z) {   // a symmetric 3 x 3 -> eigenvalues on it
 }
 
 template <typename T>
-int spectral_init_t(bb_solver *s, int n_iter, const double *v0) {
+int spectral_init_t(bb_solver *s, int n_iter, const double *v0, double tol, int *iters_done,
+                    double *residual_out) {
     const int64_t n = s->L.n_bins, n_pad = s->L.n_pad, n3 = n_pad * 3;
     if (!s->d_mv_in) BB_TRY(dev_alloc((char **)&s->d_mv_in, n3 * (int64_t)sizeof(T)));
     // V, Z: (n_pad,3) doubles; dS: 12 sums (the two host steps at the end); dP0 / dP1: the
@@ -2370,7 +2371,7 @@ int spectral_init_t(bb_solver *s, int n_iter, const double *v0) {
     // producer's while it writes its own); dF: rank-loss flag
     bb::DevBuf bV, bZ, bS, bP, bF;
     if (bV.alloc((size_t)n3 * 8) != hipSuccess || bZ.alloc((size_t)n3 * 8) != hipSuccess ||
-        bS.alloc(12 * 8) != hipSuccess || bP.alloc((size_t)2 * kSpMaxGroups * 12 * 8) != hipSuccess ||
+        bS.alloc(24 * 8) != hipSuccess || bP.alloc((size_t)2 * kSpMaxGroups * 12 * 8) != hipSuccess ||
         bF.alloc(sizeof(int)) != hipSuccess)
         return bb::fail(BB_ERR_NOMEM, "bb_solver_spectral_init: out of device memory");
     double *dV = (double *)bV.p, *dZ = (double *)bZ.p, *dS = (double *)bS.p;
@@ -2413,16 +2414,46 @@ int spectral_init_t(bb_solver *s, int n_iter, const double *v0) {
     BB_HIP_CHECK(hipMemcpyAsync(dZ, v0, (size_t)n * 24, hipMemcpyHostToDevice, st));
     BB_HIP_CHECK(bb::launch(sp_stats_kernel<double>, ggrp, bwg, 0, st, (const double *)dZ, n, n_pad, dP1));
     BB_TRY(orthonormalise());
+    // tol > 0: after every product but the first (a random V cannot have converged), the
+    // relative distance of Z = B V from span(V), ||Z - V (V^T Z)||_F / ||Z||_F -- from the
+    // Gram matrix V^T Z and the sums of Z^T Z the product left in dP1: V is orthonormal, so
+    // the squared distance is ||Z||_F^2 - ||V^T Z||_F^2 (the difference of two sums resolves
+    // a ratio down to about 1e-7).  Below tol the loop ends; the product just made is the
+    // Rayleigh-Ritz step's.  Costs two small kernels and a read of 24 doubles per product.  Every
+    // rank holds the same V and Z bit for bit (the summed products are identical on all
+    // ranks), so all ranks leave at the same product.
+    double zsums[12];
+    double residual = -1.0;
+    int done = 0;
+    bool have_product = false;
     for (int it = 0; it < n_iter; ++it) {
         BB_TRY(apply_B());
+        if (tol > 0.0 && it > 0) {
+            BB_HIP_CHECK(bb::launch(gram3_kernel<double, double>, dim3(1), dim3(1024), 0, st,
+                                    (const double *)dV, (const double *)dZ, n, dS));
+            BB_HIP_CHECK(bb::launch(sp_fold_partials_kernel, dim3(1), dim3(64), 0, st,
+                                    (const double *)dP1, groups, dS + 12));
+            BB_TRY(fetch_sums());
+            BB_HIP_CHECK(hipMemcpy(zsums, dS + 12, sizeof(zsums), hipMemcpyDeviceToHost));
+            double gg = 0.0;
+            const double zz = zsums[0] + zsums[4] + zsums[8];
+            for (int q = 0; q < 9; ++q) gg += sums[q] * sums[q];
+            residual = zz > 0.0 ? sqrt(std::max(0.0, zz - gg) / zz) : 0.0;
+            if (residual < tol) { have_product = true; break; }
+        }
         BB_TRY(orthonormalise());
+        done = it + 1;
     }
+    if (iters_done) *iters_done = done;
+    if (residual_out) *residual_out = residual;
     // Rayleigh-Ritz on span(V): M = sym(V^T B V), X0 = V E sqrt(max(lambda, 0)).  From here on
     // the host takes part: three reads of 12 doubles for the whole start.
-    BB_TRY(apply_B());
-    BB_HIP_CHECK(bb::launch(gram3_kernel<double, double>, dim3(1), dim3(1024), 0, st, (const double *)dV,
-                            (const double *)dZ, n, dS));
-    BB_TRY(fetch_sums());
+    if (!have_product) {
+        BB_TRY(apply_B());
+        BB_HIP_CHECK(bb::launch(gram3_kernel<double, double>, dim3(1), dim3(1024), 0, st,
+                                (const double *)dV, (const double *)dZ, n, dS));
+        BB_TRY(fetch_sums());
+    }
     int lost = 0;
     BB_HIP_CHECK(hipMemcpy(&lost, dF, sizeof(int), hipMemcpyDeviceToHost));
     if (lost)
@@ -2459,9 +2490,16 @@ int spectral_init_t(bb_solver *s, int n_iter, const double *v0) {
 
 }  // namespace
 
+extern "C" int bb_solver_spectral_init_tol(bb_solver *s, int n_iter, double tol, const double *v0,
+                                           int *iters_done, double *residual);
 extern "C" int bb_solver_spectral_init(bb_solver *s, int n_iter, const double *v0) {
+    return bb_solver_spectral_init_tol(s, n_iter, 0.0, v0, nullptr, nullptr);
+}
+extern "C" int bb_solver_spectral_init_tol(bb_solver *s, int n_iter, double tol, const double *v0,
+                                           int *iters_done, double *residual) {
     BB_REQUIRE(s != nullptr && v0 != nullptr, "bb_solver_spectral_init: NULL argument");
     BB_REQUIRE(n_iter >= 0 && n_iter <= 100000, "bb_solver_spectral_init: bad n_iter");
+    BB_REQUIRE(tol >= 0.0 && tol < 1.0, "bb_solver_spectral_init: need 0 <= tol < 1");
     if (!s->have_wish) return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: no wish distances set");
     if (s->world != 1 && !s->peer_connected && !s->comm)
         return bb::fail(BB_ERR_STATE, "bb_solver_spectral_init: with world > 1 the ranks need their "
@@ -2475,8 +2513,8 @@ extern "C" int bb_solver_spectral_init(bb_solver *s, int n_iter, const double *v
                                       "(start each map with a solver of its own)");
     BB_REQUIRE(s->L.n_bins >= 3, "bb_solver_spectral_init: needs at least 3 bins");
     BB_TRY(bb::enter_device(s->device));
-    const int rc = s->dtype == BB_F32 ? spectral_init_t<float>(s, n_iter, v0)
-                                      : spectral_init_t<double>(s, n_iter, v0);
+    const int rc = s->dtype == BB_F32 ? spectral_init_t<float>(s, n_iter, v0, tol, iters_done, residual)
+                                      : spectral_init_t<double>(s, n_iter, v0, tol, iters_done, residual);
     if (rc != BB_OK) return rc;
     s->have_coords = true;
     s->hist_n = 0;

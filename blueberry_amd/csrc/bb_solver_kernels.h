@@ -2355,6 +2355,15 @@ __global__ __launch_bounds__(kSpWG) void sp_stats_kernel(const TI *__restrict__ 
     sp_store_partial(acc, partial);
 }
 
+// the 12 sums themselves (groups added in order), for the stopping rule's one small read-back
+__global__ __launch_bounds__(64) void sp_fold_partials_kernel(const double *__restrict__ partial,
+                                                              int groups, double *__restrict__ out) {
+    if (threadIdx.x >= 12) return;
+    double v = 0.0;
+    for (int g = 0; g < groups; ++g) v += partial[(int64_t)g * 12 + threadIdx.x];
+    out[threadIdx.x] = v;
+}
+
 // g = R^T R (R upper) -> R^-1 (upper), 3 x 3 row-major.  False if g is not positive definite.
 __host__ __device__ inline bool sp_chol3_inv_upper(const double *g, double *rinv) {
     double r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};

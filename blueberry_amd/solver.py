@@ -233,17 +233,22 @@ class HipEngine(object):
                    "bb_solver_matvec_sq")
         return y
 
-    def spectral_init_device(self, n_iter, v0):
-        """Classical-MDS start computed and left on the device: `bb_solver_spectral_init`.
+    def spectral_init_device(self, n_iter, v0, tol=0.0):
+        """Classical-MDS start computed and left on the device: `bb_solver_spectral_init_tol`.
         v0: (n_bins, 3) start of the block power iteration (the same on every rank).  With
         several ranks it is collective and needs their exchange set up first (peer arenas or
         the library's communicator): the per-rank products are summed on the device, nothing
-        of size N crosses PCIe.  Raises RankDeficient when the iterate lost rank."""
+        of size N crosses PCIe.  tol > 0: n_iter is the most products made; the loop ends once
+        B V lies within tol (relative) of span(V).  Returns (products orthonormalised, last
+        distance read or -1).  Raises RankDeficient when the iterate lost rank."""
         v0 = _check_coords(v0, self.n_bins)
-        rc = self._lib.bb_solver_spectral_init(self._h, int(n_iter), _lib.as_f64_ptr(v0))
+        done, res = _lib.c_int(), _lib.c_dbl()
+        rc = self._lib.bb_solver_spectral_init_tol(self._h, int(n_iter), float(tol),
+                                                   _lib.as_f64_ptr(v0), done, res)
         if rc == _lib.BB_ERR_STATE and "lost rank" in _lib.last_error():
             raise RankDeficient(_lib.last_error())
-        _lib.check(rc, "bb_solver_spectral_init")
+        _lib.check(rc, "bb_solver_spectral_init_tol")
+        return int(done.value), float(res.value)
 
     def stress(self):
         out = _lib.c_dbl()
@@ -635,6 +640,10 @@ class StructureSolver(object):
     init : 'random' or 'spectral'
         Start used when `fit()` gets no `init=` array: seeded standard normal, or
         classical MDS computed on the device (`spectral_init`).
+    spectral_iter, spectral_tol : int, float
+        The spectral start's block power iteration makes at most `spectral_iter` products
+        and ends once B V lies within `spectral_tol` (relative) of span(V); 0 = always
+        `spectral_iter` products.  `spectral_iterations_` tells how many were made.
     momentum : float in [0, 1)
         Heavy-ball coefficient mu: V <- mu V - lr g, X <- X + V.  0 = plain steps.
     device : int or None
@@ -664,7 +673,7 @@ class StructureSolver(object):
 
     def __init__(self, n_iter=100, lr="auto", dtype="float32", alpha=3.0, kind="counts",
                  seed=0, device=None, distributed=None, engine=None, momentum=0.0,
-                 init="random", tol=None, check_every=10):
+                 init="random", tol=None, check_every=10, spectral_iter=40, spectral_tol=1e-3):
         if dtype not in _DTYPES:
             raise ValueError("dtype must be 'float32' or 'float64'")
         if kind not in _KINDS:
@@ -689,6 +698,9 @@ class StructureSolver(object):
         if init not in ("random", "spectral"):
             raise ValueError("init must be 'random' or 'spectral' (or pass init= to fit())")
         self.init = init
+        if int(spectral_iter) < 0 or not 0.0 <= float(spectral_tol) < 1.0:
+            raise ValueError("need spectral_iter >= 0 and 0 <= spectral_tol < 1")
+        self.spectral_iter, self.spectral_tol = int(spectral_iter), float(spectral_tol)
         self.n_iter, self.lr, self.dtype, self.alpha, self.kind, self.seed = (
             int(n_iter), lr, dtype, float(alpha), kind, int(seed))
         self.device, self.distributed = device, distributed
@@ -775,7 +787,8 @@ class StructureSolver(object):
                     world == 1 or getattr(eng, "_comm_state", None) in ("peer", "rccl"))
                 if device_form:
                     try:
-                        eng.spectral_init_device(40, v0)
+                        info = eng.spectral_init_device(self.spectral_iter, v0, tol=self.spectral_tol)
+                        self.spectral_iterations_ = info[0] if info else self.spectral_iter
                         on_device = True
                     except RankDeficient:
                         pass
@@ -785,7 +798,9 @@ class StructureSolver(object):
                         on_device = _all_ranks(on_device)
             if not on_device:
                 if init is None:                   # 'spectral', host-driven
-                    init = spectral_init(eng, n, world, seed=self.seed)
+                    init, self.spectral_iterations_ = spectral_init(
+                        eng, n, world, n_iter=self.spectral_iter, seed=self.seed,
+                        tol=self.spectral_tol, return_iterations=True)
                 eng.set_coords(init)
             if self.momentum:
                 eng.set_momentum(self.momentum)
@@ -969,6 +984,8 @@ class StructureSolver(object):
                 one = StructureSolver(n_iter=0, lr=self.lr, dtype=self.dtype, alpha=self.alpha,
                                       kind=self.kind, seed=self.seed, device=device,
                                       distributed=False, init="spectral",
+                                      spectral_iter=self.spectral_iter,
+                                      spectral_tol=self.spectral_tol,
                                       engine=self._engine_factory).fit(maps[m])
                 init = one.structure_
             elif init is None:
@@ -1013,7 +1030,7 @@ class StructureSolver(object):
         return self.fit(X, init=init).structure_
 
 
-def spectral_init(eng, n, world, n_iter=40, seed=0):
+def spectral_init(eng, n, world, n_iter=40, seed=0, tol=0.0, return_iterations=False):
     """Classical-MDS start: the top three eigenpairs of B = -1/2 J (D o D) J,
     J = I - 11'/n, by block power iteration with a Rayleigh-Ritz step, using the
     device matvec over the resident units (`bb_solver_matvec_sq`); X0 = V sqrt(L).
@@ -1022,8 +1039,10 @@ def spectral_init(eng, n, world, n_iter=40, seed=0):
     `HipEngine.spectral_init_device` runs the same iteration without leaving the device.
     Exact (up to a rigid motion) for a complete, noise-free distance matrix; for
     incomplete maps the missing pairs count as zero distance, so it is a start,
-    not a solution.  Plays the part SURVEY.md 8(f)-2 assigns to the reference's
-    `ContactMap.eigenvector` (`blueberry/datatypes.pyx:216-235`)."""
+    not a solution.  tol > 0: the stopping rule of `bb_solver_spectral_init_tol` (after every
+    product but the first, ||Z - V V'Z||_F / ||Z||_F < tol ends the loop).  Plays the part
+    SURVEY.md 8(f)-2 assigns to the reference's `ContactMap.eigenvector`
+    (`blueberry/datatypes.pyx:216-235`)."""
     def apply_B(V):
         U = V - V.mean(axis=0)
         W = eng.matvec_sq(U)
@@ -1048,9 +1067,17 @@ def spectral_init(eng, n, world, n_iter=40, seed=0):
 
     G0 = numpy.random.default_rng(seed).standard_normal((n, 3))
     V = orth(G0)
-    for _ in range(int(n_iter)):
-        V = orth(apply_B(V))
-    Z = apply_B(V)
+    done, Z = 0, None
+    for it in range(int(n_iter)):
+        Z = apply_B(V)
+        if tol > 0.0 and it > 0:
+            zz, G = float((Z * Z).sum()), V.T @ Z
+            if (numpy.sqrt(max(0.0, zz - float((G * G).sum())) / zz) if zz > 0.0 else 0.0) < tol:
+                break
+        V, Z = orth(Z), None
+        done = it + 1
+    if Z is None:
+        Z = apply_B(V)
     evals, evecs = numpy.linalg.eigh(0.5 * (V.T @ Z + Z.T @ V))       # Rayleigh-Ritz, 3x3
     order = numpy.argsort(evals)[::-1]
     U = V @ evecs[:, order]
@@ -1058,7 +1085,8 @@ def spectral_init(eng, n, world, n_iter=40, seed=0):
     # need not agree): every Ritz vector is turned to the side of the start's first column,
     # here and in bb_solver_spectral_init, so one seed gives one start on every world size
     U = U * numpy.where(U.T @ G0[:, 0] < 0.0, -1.0, 1.0)
-    return U * numpy.sqrt(numpy.maximum(evals[order], 0.0))
+    x0 = U * numpy.sqrt(numpy.maximum(evals[order], 0.0))
+    return (x0, done) if return_iterations else x0
 
 
 def _all_ranks(ok):

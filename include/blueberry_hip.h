@@ -342,6 +342,19 @@ BB_API int bb_solver_matvec_sq(bb_solver *s, const double *x, double *y);
  * (blueberry/datatypes.pyx:216-235). */
 BB_API int bb_solver_spectral_init(bb_solver *s, int n_iter, const double *v0);
 
+/* The same start with a stopping rule: `n_iter` is the most products the loop makes; after
+ * every product but the first the relative distance of Z = B V from span(V),
+ * ||Z - V (V^T Z)||_F / ||Z||_F, is read back (24 doubles) and the loop ends
+ * once it is below `tol` (0 = never: exactly bb_solver_spectral_init; the difference of sums
+ * it is formed from resolves it down to about 1e-7, the fp32 sweep to about 1e-6).  A complete
+ * noise-free map has rank 3 and ends after two products instead of `n_iter`; a noisy or
+ * incomplete one runs until the third and fourth eigenvalue have separated that far.
+ * `iters_done` (optional) = orthonormalised products made; `residual` (optional) = the last
+ * distance read, -1 if none was.  world > 1: the ranks hold identical V and Z, so all of them
+ * leave at the same product. */
+BB_API int bb_solver_spectral_init_tol(bb_solver *s, int n_iter, double tol, const double *v0,
+                                       int *iters_done, double *residual);
+
 /* Stress of the current coordinates (one gradient pass, no update). */
 BB_API int bb_solver_stress(bb_solver *s, double *stress);
 /* Copies the stress history (one value per completed iteration since the

@@ -110,10 +110,10 @@ def _spectral_worker(rank, world, port, n, fail_rank, q):
             return host_form(*a, **k)
 
         class Eng(OracleEngine):
-            def spectral_init_device(self, n_iter, v0):
+            def spectral_init_device(self, n_iter, v0, tol=0.0):
                 assert self._comm_state == "peer", "the exchange must be chosen first"
                 log.append("device")
-                x = host_form(self, self.n_bins, self.world, n_iter=n_iter, seed=0)   # collective
+                x = host_form(self, self.n_bins, self.world, n_iter=n_iter, seed=0, tol=tol)   # collective
                 if rank == fail_rank:
                     raise solver.RankDeficient("the iterate lost rank (scripted)")
                 self.set_coords(x)

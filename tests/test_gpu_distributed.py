@@ -531,6 +531,14 @@ def test_multi_rank_spectral_start_stays_on_the_device(dtype, tol, world, form, 
     one.set_wish_dense(w, "wish", 3.0)
     one.spectral_init_device(40, v0)
     X1 = one.get_coords()
+    # (the stopping rule: every rank must leave the loop at the same product -- they hold
+    # the same V and Z bit for bit -- and at the product one rank alone leaves at)
+    hole = numpy.triu(numpy.random.default_rng(5).random((n, n)) < 0.1, 1)
+    wm = w.copy()
+    wm[hole | hole.T] = 0.0
+    one.set_wish_dense(wm, "wish", 3.0)
+    done1 = one.spectral_init_device(80, v0, tol=1e-3)[0]
+    X1m = one.get_coords()
     one.close()
     engs = _peer_engines(world, n, dtype, w, v0)
     assert all(e.peer_form() == form for e in engs)
@@ -569,6 +577,30 @@ def test_multi_rank_spectral_start_stays_on_the_device(dtype, tol, world, form, 
     d = _oracle.wish_from_coords(Xs[0])
     assert numpy.abs(d - w).max() < (1e-6 if dtype == "float64" else 1e-3) * w.max()
     assert all(numpy.array_equal(h, hs[0]) for h in hs) and hs[0].shape == (3,)
+    engs = _peer_engines(world, n, dtype, wm, v0)
+    dones = [None] * world
+
+    def run_tol(r):
+        try:
+            dones[r] = engs[r].spectral_init_device(80, v0, tol=1e-3)[0]
+        except Exception as exc:                  # noqa: BLE001
+            errs.append(exc)
+
+    threads = [threading.Thread(target=run_tol, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errs, errs
+    assert 1 < done1 < 80 and all(abs(d - done1) <= (0 if dtype == "float64" else 1) for d in dones)
+    assert len(set(dones)) == 1
+    Xm = [e.get_coords() for e in engs]
+    for e in engs:
+        assert e.peer_status() == 0
+        e.close()
+    assert all(numpy.array_equal(X, Xm[0]) for X in Xm[1:])
+    if dones[0] == done1:
+        assert numpy.abs(Xm[0] - X1m).max() < 1e3 * tol * numpy.abs(X1m).max()
 
 
 def _worker_spectral_fit(rank, world, port, n, dtype, comm, q):

@@ -1128,6 +1128,52 @@ def test_spectral_init_recovers_exact_distances():
     assert numpy.isfinite(sp.structure_).all() and sp.stress_[-1] < rd.stress_[-1]
 
 
+@pytest.mark.parametrize("dtype,rtol", [("float64", 1e-9), ("float32", 1e-3)])
+def test_spectral_start_stopping_rule_on_the_device(dtype, rtol):
+    """bb_solver_spectral_init_tol: the device loop and the host-driven loop follow one rule
+    -- same number of products, same start -- on a complete map (rank 3: one orthonormalised
+    product) and on an incomplete one (many); tol = 0 is bb_solver_spectral_init exactly."""
+    from blueberry_amd.solver import spectral_init
+    n = 1500
+    w = _oracle.wish_from_coords(_oracle.random_walk(n))
+    v0 = numpy.random.default_rng(0).standard_normal((n, 3))
+    hole = numpy.triu(numpy.random.default_rng(5).random((n, n)) < 0.1, 1)
+    wm = w.copy()
+    wm[hole | hole.T] = 0.0
+    e = HipEngine(n, dtype)
+    e.set_wish_dense(w, "wish", 3.0)
+    done, res = e.spectral_init_device(40, v0, tol=1e-3)
+    x_dev = e.get_coords()
+    x_host, done_host = spectral_init(e, n, 1, seed=0, tol=1e-3, return_iterations=True)
+    assert done == done_host == 1 and 0.0 <= res < 1e-3
+    assert numpy.abs(x_dev - x_host).max() < 10 * rtol * w.max()
+    assert numpy.abs(_oracle.wish_from_coords(x_dev) - w).max() < max(rtol, 1e-6) * w.max()
+    assert e.spectral_init_device(5, v0) == (5, -1.0)            # no rule: all of them, nothing read
+    x5 = e.get_coords()
+    lib = _lib.load()
+    _lib.check(lib.bb_solver_spectral_init(e._h, 5, _lib.as_f64_ptr(v0)), "bb_solver_spectral_init")
+    assert numpy.array_equal(e.get_coords(), x5)
+    e.set_wish_dense(wm, "wish", 3.0)
+    for t in (1e-2, 1e-3):
+        done, res = e.spectral_init_device(80, v0, tol=t)
+        x_dev = e.get_coords()
+        x_host, done_host = spectral_init(e, n, 1, n_iter=80, seed=0, tol=t, return_iterations=True)
+        assert 1 < done < 80 and abs(done - done_host) <= (0 if dtype == "float64" else 1), (t, done, done_host)
+        assert res < t
+        if done == done_host:
+            assert numpy.abs(x_dev - x_host).max() < 1e3 * rtol * numpy.abs(x_host).max()
+    done_tight, res = e.spectral_init_device(3, v0, tol=1e-6)
+    assert done_tight == 3 and res >= 1e-6                        # the cap holds
+    with pytest.raises(ValueError, match="tol"):
+        e.spectral_init_device(5, v0, tol=1.0)
+    e.close()
+    s = bb.StructureSolver(n_iter=2, dtype=dtype, kind="wish", init="spectral").fit(w)
+    assert s.spectral_iterations_ == 1
+    s = bb.StructureSolver(n_iter=2, dtype=dtype, kind="wish", init="spectral", spectral_tol=0.0,
+                           spectral_iter=9).fit(w)
+    assert s.spectral_iterations_ == 9
+
+
 # ---- BASELINE config 2 at its full size, directly against the oracle -----------------
 def test_solver_fp32_chr1_10kb_sized_vs_oracle(oracle):
     """N = 24,926 bins (chr1 at 10 kb), fp32, tol 1e-5 vs the fp64 oracle on the

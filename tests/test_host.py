@@ -197,6 +197,39 @@ def test_spectral_init_host_loop_is_classical_mds():
     assert (x0.T @ p > 0).all()
 
 
+def test_spectral_start_stopping_rule_host_form():
+    """spectral_tol: a complete noise-free map has a rank-3 B, so the second product already
+    lies in span(V) and the loop ends after ONE orthonormalised product with the start the
+    fixed 40 give; tol = 0 makes exactly spectral_iter; an incomplete map takes more products
+    the tighter the tolerance."""
+    from tests._engines import OracleEngine
+    from tests import _oracle
+    from blueberry_amd.solver import spectral_init
+    n = 150
+    w = _oracle.wish_from_coords(_oracle.random_walk(n))
+    eng = OracleEngine(n, "float64")
+    eng.set_wish_dense(w, "wish", 3.0)
+    x40 = spectral_init(eng, n, 1, seed=0)
+    xt, done = spectral_init(eng, n, 1, seed=0, tol=1e-3, return_iterations=True)
+    assert done == 1 and numpy.abs(xt - x40).max() < 1e-8 * numpy.abs(x40).max()
+    assert spectral_init(eng, n, 1, n_iter=7, seed=0, return_iterations=True)[1] == 7
+    hole = numpy.triu(numpy.random.default_rng(5).random((n, n)) < 0.1, 1)
+    wm = w.copy()
+    wm[hole | hole.T] = 0.0
+    eng.set_wish_dense(wm, "wish", 3.0)
+    counts = [spectral_init(eng, n, 1, n_iter=80, seed=0, tol=t, return_iterations=True)[1]
+              for t in (1e-1, 3e-2, 1e-2, 1e-9)]
+    assert 1 < counts[0] < counts[1] < counts[2] < counts[3] == 80
+    s = bb.StructureSolver(n_iter=1, dtype="float64", kind="wish", init="spectral",
+                           distributed=False, engine=OracleEngine, spectral_tol=3e-2,
+                           spectral_iter=80).fit(wm)
+    assert s.spectral_iterations_ == counts[1]
+    with pytest.raises(ValueError):
+        bb.StructureSolver(spectral_tol=1.5)
+    with pytest.raises(ValueError):
+        bb.StructureSolver(spectral_iter=-1)
+
+
 @pytest.mark.parametrize("n", [2, 3])
 def test_spectral_init_on_two_and_three_bins(n):
     """numpy's QR of a (2, 3) start has 2 columns; the host loop pads the missing
