@@ -140,7 +140,10 @@ BB_API int bb_solver_set_wish_dense(bb_solver *s, const double *host, int64_t ld
  *                                 and the stress is kept PER MAP: bb_solver_get_stress_history
  *                                 then returns n_maps values per iteration (iteration-major)
  *   bb_solver_set_wish_dense_block  map m's (n_sub, n_sub) host matrix into its bins
- *                                 [bin_offset, bin_offset + n_sub); as bb_solver_set_wish_dense
+ *                                 [bin_offset, bin_offset + n_sub); as bb_solver_set_wish_dense.
+ *                                 A map ends where its last tile ends: the pairs of the tiles
+ *                                 the block touches that lie outside the block are cleared
+ *                                 (no constraint); other tiles keep what they hold
  *   bb_solver_stress_maps         per-map stress of the current coordinates
  * Coordinates travel as one (n_bins, 3) array (rows between the maps are padding: 0). */
 BB_API int bb_solver_set_maps(bb_solver *s, int n_maps, const int64_t *bin_begin,
