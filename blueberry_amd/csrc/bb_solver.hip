@@ -14,6 +14,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cmath>
 #include <type_traits>
 #include <vector>
 
@@ -107,6 +108,9 @@ struct bb_solver {
     // iteration (row_owner_kernel); the units stay resident too and serve every other
     // entry point (grad / apply, stress, matvec)
     bool row_owner = false;
+    bool row_owner_built = false;        // created with the row-owner buffers (row_owner can be
+                                         // switched off later: several maps, block steps)
+    bool block_steps = false;            // d_blk_scale set by bb_solver_set_block_steps
     void *d_full = nullptr, *d_X2 = nullptr;
     int64_t full_ld = 0;
     double *d_ro_part = nullptr;   // 2 x ro_blocks per-workgroup stress sums (ping-pong)
@@ -560,7 +564,8 @@ void fill_reduce_params(bb_solver *s, ReduceParams<T> &p, int mode, double lr, d
     p.mode = mode;
     p.stress_slot = s->d_stress_slot;
     p.n_slots = s->n_slots;
-    p.blk_scale = (const T *)s->d_blk_scale;
+    // (scale 1 is a plain sum -- the matvec, the spectral start's products: never scaled)
+    p.blk_scale = scale == 1.0 ? nullptr : (const T *)s->d_blk_scale;
     p.map_ptr = s->d_map_ptr;
     p.map_idx = s->d_map_idx;
     p.n_maps = s->n_maps;
@@ -832,7 +837,7 @@ int bb_solver_create(bb_solver **out, int64_t n_bins, int dtype, int device, int
     s->world = world;
     int rc = bb_layout_dense_info(n_bins, dtype, &s->L);
     s->wide = bb::wide_layout(dtype, n_bins);
-    s->row_owner = world == 1 && n_bins <= row_owner_max();
+    s->row_owner = s->row_owner_built = world == 1 && n_bins <= row_owner_max();
     if (rc == BB_OK) {
         if (tile_I == nullptr) {
             s->tile_I.resize((size_t)s->L.n_tiles);
@@ -996,6 +1001,7 @@ int bb_solver_set_maps(bb_solver *s, int n_maps, const int64_t *bin_begin, const
     if (idx.empty()) idx.push_back(0);
     hipFree(s->d_blk_scale); hipFree(s->d_map_ptr); hipFree(s->d_map_idx); hipFree(s->d_map_scalar);
     s->d_blk_scale = nullptr; s->d_map_ptr = s->d_map_idx = nullptr; s->d_map_scalar = nullptr;
+    s->block_steps = false;        // (the maps' steps replace a bb_solver_set_block_steps)
     s->n_maps = 1;                 // (what holds if an allocation below fails: one map, no tables)
     s->map_begin.clear();
     BB_TRY(dev_alloc((char **)&s->d_blk_scale, nb * es));
@@ -1013,6 +1019,43 @@ int bb_solver_set_maps(bb_solver *s, int n_maps, const int64_t *bin_begin, const
     s->map_begin.assign(bin_begin, bin_begin + n_maps + 1);
     s->row_owner = false;          // the sweep: its reduce knows the maps
     s->hist_n = 0;
+    return BB_OK;
+}
+
+int bb_solver_set_block_steps(bb_solver *s, const double *scale, int64_t n_blocks) {
+    BB_REQUIRE(s != nullptr, "bb_solver_set_block_steps: solver is NULL");
+    if (s->n_maps > 1)
+        return bb::fail(BB_ERR_STATE, "bb_solver_set_block_steps: a solver of several maps has its "
+                                      "steps from bb_solver_set_maps");
+    if (s->grad_pending)
+        return bb::fail(BB_ERR_STATE, "bb_solver_set_block_steps: a bb_solver_grad is pending");
+    BB_TRY(bb::enter_device(s->device));
+    if (scale == nullptr) {                       // back to one step for all
+        BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+        hipFree(s->d_blk_scale);
+        s->d_blk_scale = nullptr;
+        s->block_steps = false;
+        if (s->row_owner_built && !s->row_owner) {
+            s->row_owner = true;
+            if (s->have_wish) BB_TRY(refresh_full(s));
+        }
+        return BB_OK;
+    }
+    const int64_t nb = s->L.n_blocks, es = bb::elem_size(s->dtype);
+    BB_REQUIRE(n_blocks == nb, "bb_solver_set_block_steps: one factor per block of the layout "
+                               "(bb_solver_layout: n_blocks)");
+    std::vector<char> host((size_t)(nb * es));
+    for (int64_t b = 0; b < nb; ++b) {
+        BB_REQUIRE(std::isfinite(scale[b]) && scale[b] > 0.0,
+                   "bb_solver_set_block_steps: factors must be finite and positive");
+        if (s->dtype == BB_F32) ((float *)host.data())[b] = (float)scale[b];
+        else ((double *)host.data())[b] = scale[b];
+    }
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (!s->d_blk_scale) BB_TRY(dev_alloc((char **)&s->d_blk_scale, nb * es));
+    BB_HIP_CHECK(hipMemcpy(s->d_blk_scale, host.data(), host.size(), hipMemcpyHostToDevice));
+    s->block_steps = true;
+    s->row_owner = false;          // the sweep: its reduce knows the blocks
     return BB_OK;
 }
 

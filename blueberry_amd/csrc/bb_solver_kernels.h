@@ -1241,8 +1241,11 @@ struct ReduceParams {
     T lr;
     const double *__restrict__ stress_slot;  // per private column slot (see the sweep)
     int n_slots;
-    // several maps in one solver (bb_solver_set_maps; world = 1): the step of block b is
-    // lr * blk_scale[b], and the stress is folded per map -- map m's partials are
+    // a step per block (bb_solver_set_block_steps; bb_solver_set_maps: the map's): the
+    // gradient of block b leaves the reduce as blk_scale[b] * g -- into the update, the
+    // exchange buffer or the peers' arenas alike, so every rank and every later kernel steps
+    // with the one uniform lr (nullptr for a plain sum: the matvec).  Several maps
+    // (world = 1): the stress is folded per map -- map m's partials are
     // map_idx[map_ptr[m] .. map_ptr[m + 1]) (index < n_waves: stresspart, else stress_slot) --
     // into stress_out[m].  n_maps <= 1: one map, every partial, stress_out[0].
     const T *__restrict__ blk_scale;
@@ -1305,11 +1308,10 @@ __global__ __launch_bounds__(kRedWG) void reduce_kernel(ReduceParams<T> p) {
         if (p.mode == kReducePartial) {
             p.part_out[o] = acc;
         } else {
-            const T g = p.scale * acc;
+            const T g = p.blk_scale ? p.blk_scale[b] * (p.scale * acc) : p.scale * acc;
             if (p.mode == kReduceApply) {
                 // SPEC 2.4: V <- mu V - lr g ; X <- X + V   (mu = 0: X -= lr g)
-                const T lr = p.blk_scale ? p.lr * p.blk_scale[b] : p.lr;
-                const T v = p.mu * p.V[o] - lr * g;
+                const T v = p.mu * p.V[o] - p.lr * g;
                 p.V[o] = v;
                 p.X[o] += v;
             } else if (p.mode == kReducePeer) {
@@ -1423,11 +1425,10 @@ __global__ __launch_bounds__(128 * S) void reduce_sliced_kernel(ReduceParams<T> 
             T tot = meet[0][el];
 #pragma unroll
             for (int q = 1; q < S; ++q) tot += meet[q][el];
-            const T g = p.scale * tot;
+            const T g = p.blk_scale ? p.blk_scale[b] * (p.scale * tot) : p.scale * tot;
             if (p.mode == kReduceApply) {
                 // SPEC 2.4: V <- mu V - lr g ; X <- X + V   (mu = 0: X -= lr g)
-                const T lr = p.blk_scale ? p.lr * p.blk_scale[b] : p.lr;
-                const T v = p.mu * vo - lr * g;
+                const T v = p.mu * vo - p.lr * g;
                 p.V[o] = v;
                 p.X[o] = xo + v;
             } else if (p.mode == kReducePeer) {
@@ -1670,7 +1671,7 @@ __global__ __launch_bounds__(128 * S) void reduce_exchange_kernel(
         T tot = meet[0][el];
 #pragma unroll
         for (int q = 1; q < S; ++q) tot += meet[q][el];
-        const T mine = peer_sendable(p.scale * tot);
+        const T mine = peer_sendable(p.blk_scale ? p.blk_scale[b] * (p.scale * tot) : p.scale * tot);
         for (int q = 0; q < R; ++q)
             __hip_atomic_store(xt->dst[q] + o, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         T g;

@@ -189,6 +189,19 @@ class HipEngine(object):
             self._h, dev_matrix._h, int(bin_offset), _KINDS[kind], float(alpha)),
             "bb_solver_set_wish_from_cm_block")
 
+    def set_block_steps(self, scale):
+        """A step per block of the layout (`bb_solver_set_block_steps`): bin i moves by
+        lr * scale[i // vw] * g_i; None = one step for all again."""
+        if scale is None:
+            _lib.check(self._lib.bb_solver_set_block_steps(self._h, None, 0),
+                       "bb_solver_set_block_steps")
+            return
+        sc = numpy.ascontiguousarray(scale, dtype=numpy.float64)
+        if sc.ndim != 1:
+            raise ValueError("scale must be one factor per block")
+        _lib.check(self._lib.bb_solver_set_block_steps(self._h, _lib.as_f64_ptr(sc), sc.shape[0]),
+                   "bb_solver_set_block_steps")
+
     def stress_maps(self):
         out = numpy.empty(getattr(self, "n_maps", 1), dtype=numpy.float64)
         _lib.check(self._lib.bb_solver_stress_maps(self._h, _lib.as_f64_ptr(out), out.shape[0]),
@@ -561,16 +574,30 @@ def tiles_from_blocks(n_bins, boundaries, band_bins, dtype):
     return (ti, tj), pairs
 
 
-def max_degree(n_bins, tiles, dtype):
-    """Upper bound on the number of stored partners of any bin under a tile list: the step
-    1 / (2 * max_degree) is inside the majorisation bound (docs/SPEC.md 2.4), as 1 / (2 N)
-    is for a dense map."""
+def block_degrees(n_bins, tiles, dtype):
+    """Per block of the layout: an upper bound on the number of stored partners of its bins
+    under a tile list (tiles in the block's row and column, times the tile edge)."""
     vw = layout_info(n_bins, dtype)["vw"]
     nb = (int(n_bins) + vw - 1) // vw
     ti, tj = numpy.asarray(tiles[0]), numpy.asarray(tiles[1])
     deg = numpy.bincount(ti, minlength=nb) + numpy.bincount(tj, minlength=nb)
     deg -= numpy.bincount(ti[ti == tj], minlength=nb)             # a diagonal tile counts once
-    return int(min(int(n_bins), deg.max() * vw))
+    return numpy.minimum(int(n_bins), deg * vw).astype(numpy.int64)
+
+
+def max_degree(n_bins, tiles, dtype):
+    """Upper bound on the number of stored partners of any bin under a tile list: the step
+    1 / (2 * max_degree) is the one SPEC 2.4 gives a dense map of that many bins."""
+    return int(block_degrees(n_bins, tiles, dtype).max())
+
+
+def block_step_factors(n_bins, tiles, dtype):
+    """(lr, scale) of SPEC 2.4.1 for a tile list: lr = 1 / (2 max_degree) and, per block,
+    scale[b] = max_degree / degree[b] -- every block takes the step 1 / (2 degree[b]) its own
+    number of stored partners allows (a block without tiles keeps the factor 1)."""
+    deg = block_degrees(n_bins, tiles, dtype)
+    top = int(deg.max()) if deg.size and deg.max() > 0 else int(n_bins)
+    return 1.0 / (2.0 * top), numpy.where(deg > 0, top / numpy.maximum(deg, 1), 1.0)
 
 
 def allreduce_exchange(t):
@@ -640,6 +667,12 @@ class StructureSolver(object):
     init : 'random' or 'spectral'
         Start used when `fit()` gets no `init=` array: seeded standard normal, or
         classical MDS computed on the device (`spectral_init`).
+    block_steps : bool
+        Blocked-sparse input only (scipy.sparse matrices, `fit_triples`): a step per block of
+        the tile layout, 1 / (2 degree[b]) with degree[b] the block's number of stored
+        partner bins, instead of one step for all (`lr='auto'`: 1 / (2 N); SPEC 2.4.1).  A
+        whole-genome map converges in about a third of the iterations; a float `lr` is then
+        the step of the block with the most partners.  Dense input: no effect.
     spectral_iter, spectral_tol : int, float
         The spectral start's block power iteration makes at most `spectral_iter` products
         and ends once B V lies within `spectral_tol` (relative) of span(V); 0 = always
@@ -673,7 +706,8 @@ class StructureSolver(object):
 
     def __init__(self, n_iter=100, lr="auto", dtype="float32", alpha=3.0, kind="counts",
                  seed=0, device=None, distributed=None, engine=None, momentum=0.0,
-                 init="random", tol=None, check_every=10, spectral_iter=40, spectral_tol=1e-3):
+                 init="random", tol=None, check_every=10, spectral_iter=40, spectral_tol=1e-3,
+                 block_steps=False):
         if dtype not in _DTYPES:
             raise ValueError("dtype must be 'float32' or 'float64'")
         if kind not in _KINDS:
@@ -701,6 +735,7 @@ class StructureSolver(object):
         if int(spectral_iter) < 0 or not 0.0 <= float(spectral_tol) < 1.0:
             raise ValueError("need spectral_iter >= 0 and 0 <= spectral_tol < 1")
         self.spectral_iter, self.spectral_tol = int(spectral_iter), float(spectral_tol)
+        self.block_steps = bool(block_steps)
         self.n_iter, self.lr, self.dtype, self.alpha, self.kind, self.seed = (
             int(n_iter), lr, dtype, float(alpha), kind, int(seed))
         self.device, self.distributed = device, distributed
@@ -753,9 +788,16 @@ class StructureSolver(object):
             tiles = tiles_from_entries(n, rows, cols, self.dtype)
         elif triples:
             tiles = matrix.tiles(n, self.dtype)
+        scale = None
+        if self.block_steps and tiles is not None:
+            lr_top, scale = block_step_factors(n, tiles, self.dtype)
+            if self.lr == "auto":
+                lr = lr_top
         eng = self._engine_factory(n, self.dtype, rank=rank, world=world,
                                    device=self._pick_device(world), tiles=tiles)
         try:
+            if scale is not None:
+                eng.set_block_steps(scale)
             if resident:
                 dev = matrix._resident()
                 if dev.device == eng.device:

@@ -44,6 +44,9 @@ class OracleEngine(object):
     def set_momentum(self, mu):
         self.mu = float(mu)
 
+    def set_block_steps(self, scale):
+        self.blk_scale = None if scale is None else numpy.asarray(scale, dtype=numpy.float64)
+
     def set_coords(self, x0):
         self.X = numpy.ascontiguousarray(x0, dtype=numpy.float64).copy()
         self.V = numpy.zeros_like(self.X)
@@ -56,6 +59,8 @@ class OracleEngine(object):
         s, g = self.oracle.stress_grad_units(self.w, self.X, self.ti, self.tj,
                                              self.info.units_per_tile, self.info.vw,
                                              self.u_begin, self.u_end)
+        if getattr(self, "blk_scale", None) is not None:     # scaled where it leaves the sum
+            g = g * numpy.repeat(self.blk_scale, self.info.vw)[:self.n_bins, None]
         self.exch[:] = 0
         self.exch[:3 * self.n_bins] = g.ravel()
         self.exch[-2] = s

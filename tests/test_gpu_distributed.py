@@ -511,6 +511,60 @@ class _CountingLib(object):
 
 @pytest.mark.parametrize("form", ["one launch", "two launches"])
 @pytest.mark.parametrize("dtype,tol,world", [("float64", 1e-12, 2), ("float32", 1e-5, 3)])
+def test_block_steps_on_several_ranks(dtype, tol, world, form, monkeypatch):
+    """bb_solver_set_block_steps on several ranks: the gradient is scaled where it leaves each
+    rank's reduce, so the peer exchange (both forms) and the two-call path with a host sum
+    step exactly as one rank does; replicas bit-identical."""
+    monkeypatch.setenv("BB_PEER_TIMEOUT_MS", "20000")
+    monkeypatch.setenv("BB_PEER_FUSED", "1" if form == "one launch" else "0")
+    from blueberry_amd.solver import HipEngine
+    from tests import _oracle
+    n, k = 2600, 5
+    lr = 1.0 / (2 * n)
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    x0 = _oracle.noisy_init(xs)
+    one = HipEngine(n, dtype)
+    scale = numpy.random.default_rng(2).uniform(0.4, 1.6, one.layout()["n_blocks"])
+    one.set_wish_dense(w, "wish", 3.0)
+    one.set_block_steps(scale)
+    one.set_momentum(0.3)
+    one.set_coords(x0)
+    one.iterate(k, lr)
+    X1, h1 = one.get_coords(), one.stress_history()
+    one.close()
+    engs = _peer_engines(world, n, dtype, w, x0, mu=0.3)
+    assert all(e.peer_form() == form for e in engs)
+    for e in engs:
+        e.set_block_steps(scale)
+    for _ in range(k):                                # ranks of one process: step by step
+        for e in engs:
+            e.iterate_peer(1, lr)
+    Xs = [e.get_coords() for e in engs]
+    hs = [e.stress_history() for e in engs]
+    for e in engs:
+        assert e.peer_status() == 0
+    for X, h in zip(Xs, hs):
+        assert numpy.abs(X - X1).max() < tol * numpy.abs(X1).max()
+        assert numpy.abs(h / h1 - 1).max() < tol
+        assert numpy.array_equal(X, Xs[0]) and numpy.array_equal(h, hs[0])
+    # the two-call path: grad, sum of the exchange buffers on the host, apply
+    for e in engs:
+        e.set_coords(x0)
+    for _ in range(k):
+        for e in engs:
+            e.grad()
+        total = sum(e.read_exchange() for e in engs)
+        for e in engs:
+            e.write_exchange(total)
+            e.apply(lr)
+    for e in engs:
+        assert numpy.abs(e.get_coords() - X1).max() < tol * numpy.abs(X1).max()
+        e.close()
+
+
+@pytest.mark.parametrize("form", ["one launch", "two launches"])
+@pytest.mark.parametrize("dtype,tol,world", [("float64", 1e-12, 2), ("float32", 1e-5, 3)])
 def test_multi_rank_spectral_start_stays_on_the_device(dtype, tol, world, form, monkeypatch):
     """init='spectral' on several ranks.  `world` ranks of this process, their
     arenas connected, each driven by a thread of its own (the start synchronises at its end;

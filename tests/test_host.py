@@ -607,5 +607,13 @@ def test_genome_boundaries_and_block_tile_list():
     cnt = numpy.bincount(i[have[i // vw, j // vw]], minlength=n) + \
         numpy.bincount(j[have[i // vw, j // vw]], minlength=n)
     assert cnt.max() <= deg <= n
+    # SPEC 2.4.1: a step per block -- every block's bound holds for each of its bins, the
+    # factors are max / own (>= 1, exactly 1 where the bound is largest)
+    from blueberry_amd.solver import block_degrees, block_step_factors
+    degs = block_degrees(n, (ti, tj), "float32")
+    assert degs.shape == (nb,) and degs.max() == deg
+    assert (cnt <= numpy.repeat(degs, vw)[:n]).all()
+    lr, scale = block_step_factors(n, (ti, tj), "float32")
+    assert lr == 1.0 / (2 * deg) and scale.min() == 1.0 and numpy.allclose(scale * degs, deg)
     with pytest.raises(ValueError):
         tiles_from_blocks(n, [0, 10, 5, n], band, "float32")
