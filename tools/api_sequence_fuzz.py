@@ -26,6 +26,7 @@ class Model(object):
         self.oracle = _oracle.load()
         self.w = self.X = self.V = self.G = None
         self.mu, self.hist, self.pending = 0.0, [], False
+        self.per_bin = None                          # bb_solver_set_block_steps, per bin
 
     def _ready(self):
         if self.w is None or self.X is None:
@@ -41,7 +42,8 @@ class Model(object):
         self.X, self.V, self.hist, self.pending = x.copy(), numpy.zeros_like(x), [], False
 
     def sg(self):
-        return self.oracle.stress_grad(self.w, self.X, f64=self.f64)
+        s, g = self.oracle.stress_grad(self.w, self.X, f64=self.f64)
+        return s, (g if self.per_bin is None else g * self.per_bin)   # scaled where it leaves the sum
 
     def iterate(self, k, lr):
         self._ready()
@@ -98,6 +100,7 @@ def one_sequence(rng, case):
     log = ["n=%d %s %s" % (n, dtype, "sweep" if sweep else "row-owner")]
     lr = 1.0 / (2 * n)
     ops = ["wish_dense", "wish_counts", "wish_sparse", "wish_coords", "wish_block", "coords", "coords",
+           "block_steps",
            "momentum", "iterate", "iterate", "grad", "apply", "apply", "stress", "matvec", "read",
            "spectral"]
     # (two sequences in three start from a solver that is ready, so most calls go through)
@@ -145,6 +148,23 @@ def one_sequence(rng, case):
                 w[:n_sub, :n_sub] = sub
                 m.set_wish(w)
                 DONE[op] = DONE.get(op, 0) + 1
+                continue
+            if op == "block_steps":
+                lay = e.layout()
+                sc = None if rng.random() < 0.3 else rng.uniform(0.3, 1.7, lay["n_blocks"])
+                try:
+                    e.set_block_steps(sc)
+                    went = True
+                except RuntimeError:
+                    went = False
+                if went == m.pending:                 # refused exactly while a gradient is pending
+                    raise AssertionError("set_block_steps went through: %s, pending: %s" % (went, m.pending))
+                if went:
+                    m.per_bin = None if sc is None else numpy.repeat(sc, lay["vw"])[:n, None]
+                    want = "units" if (sweep or sc is not None or n > 4096) else "row_owner"
+                    if e.iteration_path()[0] != want:
+                        raise AssertionError("iteration path %s, expected %s" % (e.iteration_path()[0], want))
+                    DONE[op] = DONE.get(op, 0) + 1
                 continue
             if op == "coords":
                 x = rng.standard_normal((n, 3)) * float(rng.choice([0.1, 1.0, 30.0]))
