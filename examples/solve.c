@@ -140,6 +140,38 @@ int main(void) {
         if (fabs(fabs(xm[3 * 129] - xm[3 * 128]) - 2.0) > 1e-12 || fabs(hm[3]) > 1e-20) return 11;
         if (xm[3 * 64] != 0.0) return 12;                      /* padding between the maps */
     }
+    /* The helix again, from no start at all: the classical-MDS start with its stopping rule
+     * (bb_solver_spectral_init_tol: a complete noise-free map has a rank-3 B, two products
+     * instead of forty), then a few iterations with a step per block of the layout
+     * (bb_solver_set_block_steps; all factors 1 = one step for all, here just the call). */
+    {
+        bb_layout_info lay;
+        int done = -1;
+        double res = -1.0, s_start = 0.0, v0[3 * N];
+        unsigned r = 777u;
+        for (int i = 0; i < 3 * N; i++) {
+            r = r * 1664525u + 1013904223u;
+            v0[i] = (r >> 8) / 16777216.0 - 0.5;
+        }
+        CHECK(bb_solver_create(&sol, N, BB_F64, 0, 0, 1, NULL, NULL, 0));
+        CHECK(bb_solver_set_wish_dense(sol, w, N, BB_KIND_WISH, 3.0));
+        CHECK(bb_solver_spectral_init_tol(sol, 40, 1e-3, v0, &done, &res));
+        CHECK(bb_solver_stress(sol, &s_start));
+        printf("spectral start: %d orthonormalised product(s), distance %.1e, stress %.3e (noisy start: %.3e)\n",
+               done, res, s_start, hist[0]);
+        if (done != 1 || !(res >= 0.0 && res < 1e-3) || !(s_start < 1e-9 * hist[0])) return 13;
+        CHECK(bb_solver_layout(sol, &lay, NULL, NULL));
+        double *factors = malloc(sizeof(double) * (size_t)lay.n_blocks);
+        for (int64_t b = 0; b < lay.n_blocks; b++) factors[b] = 1.0;
+        CHECK(bb_solver_set_block_steps(sol, factors, lay.n_blocks));
+        CHECK(bb_solver_iterate(sol, 2, 1.0 / (2.0 * N)));
+        CHECK(bb_solver_set_block_steps(sol, NULL, 0));
+        CHECK(bb_solver_iterate(sol, 2, 1.0 / (2.0 * N)));
+        CHECK(bb_solver_get_stress_history(sol, hist, 4, &n_hist));
+        CHECK(bb_solver_destroy(sol));
+        free(factors);
+        if (n_hist != 4) return 14;
+    }
     free(xs); free(x0); free(w);
     puts("C-ABI OK");
     return 0;
