@@ -349,8 +349,7 @@ def main():
             raise SystemExit("bench.py: --workload genome10kb is a fixed map (strong scaling)")
         tiles, pairs = tiles_from_blocks(n, genome_boundaries(n), a.band_bins, a.dtype)
         lr = 1.0 / (2 * max_degree(n, tiles, a.dtype))
-        from blueberry_amd.solver import block_step_factors
-        blk_scale = block_step_factors(n, tiles, a.dtype)[1]     # SPEC 2.4.1, the convergence legs
+        blk_scale = True                      # SPEC 2.4.1: a step per bin in the convergence legs
     eng = HipEngine(n, a.dtype, rank=rank, world=world, device=local_rank, tiles=tiles)
     eng.set_wish_from_coords(xs)          # delta_ij = |x*_i - x*_j| generated in HBM
     eng.set_coords(x0)
@@ -462,16 +461,31 @@ def main():
         conv_mu.update(converge_measured(a.momentum))
         conv_relaxed.update(converge_measured(a.relax_momentum, a.relax))
         if blk_scale is not None:
-            # a blocked-sparse map: the same three legs with a step per block
-            # (bb_solver_set_block_steps, StructureSolver(block_steps=True); SPEC 2.4.1) --
-            # every chromosome steps by its own 1 / (2 degree), not by the largest one's
-            eng.set_block_steps(blk_scale)
+            # a blocked-sparse map: the same three legs with a step per bin from the map's own
+            # degrees (bb_solver_degrees + bb_solver_set_bin_steps = StructureSolver(
+            # degree_steps=True); SPEC 2.4.1) -- every chromosome's bins step by their own
+            # 1 / (2 (degree + 1)), not by the largest one's.  The degree pass and the upload
+            # of the factors are timed too (once per map).
+            from blueberry_amd.solver import degree_step_factors, _sum_over_ranks
+            setup_ms = []
+            for _ in range(2):                # the first call of the process, then a warm one
+                fence()
+                t1 = time.perf_counter()
+                deg = _sum_over_ranks(eng.degrees(), eng, world)
+                lr_deg, factors = degree_step_factors(deg)
+                eng.set_bin_steps(factors)
+                fence()
+                setup_ms.append((time.perf_counter() - t1) * 1e3)
+            lr_uniform, lr = lr, lr_deg
             for leg, (mu_, rx_) in ((conv, (0.0, 1.0)), (conv_mu, (a.momentum, 1.0)),
                                     (conv_relaxed, (a.relax_momentum, a.relax))):
-                per_block = converge_leg(mu_, rx_)
-                per_block.update(converge_measured(mu_, rx_))
-                leg["block_steps"] = per_block
-            eng.set_block_steps(None)
+                per_bin = converge_leg(mu_, rx_)
+                per_bin.update(converge_measured(mu_, rx_))
+                per_bin["degree_pass_and_factors_ms"] = {"first_call": setup_ms[0], "warm": setup_ms[1]}
+                per_bin["degree_min_max"] = [int(deg.min()), int(deg.max())]
+                leg["degree_steps"] = per_bin
+            lr = lr_uniform
+            eng.set_bin_steps(None)
         if world == 1 and not use_dist:
             # the product's default (StructureSolver.spectral_tol = 1e-3); the fixed 41
             # products of rounds 3-4 beside it

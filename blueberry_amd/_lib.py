@@ -120,6 +120,8 @@ SIGNATURES = {
     "bb_solver_set_wish_dense_block": (c_int, [c_void_p, p_dbl, c_i64, c_i64, c_i64, c_int, c_dbl]),
     "bb_solver_stress_maps": (c_int, [c_void_p, p_dbl, c_int]),
     "bb_solver_set_block_steps": (c_int, [c_void_p, p_dbl, c_i64]),
+    "bb_solver_set_bin_steps": (c_int, [c_void_p, p_dbl, c_i64]),
+    "bb_solver_degrees": (c_int, [c_void_p, p_i64, c_i64]),
     "bb_contactmap_scatter": (c_int, [p_dbl, c_i64, c_i32, p_dbl, c_i64, c_int]),
     "bb_contactmap_normalize": (c_int, [p_dbl, c_i64, p_dbl, p_dbl, c_int]),
     "bb_benjamini_hochberg": (c_int, [p_dbl, c_i64, c_i64, p_dbl, c_int]),

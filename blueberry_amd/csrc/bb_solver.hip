@@ -57,7 +57,7 @@ struct bb_solver {
     std::vector<int32_t> wave_last_strip;  // strip each wave ends in, -1: no units
     // several maps in one solver (bb_solver_set_maps)
     int n_maps = 1;
-    void *d_blk_scale = nullptr;         // T per block: the map's step
+    void *d_bin_scale = nullptr;         // T per bin (n_pad): the factor on its gradient
     int *d_map_ptr = nullptr, *d_map_idx = nullptr;
     double *d_map_scalar = nullptr;      // per-map stress of bb_solver_stress_maps
     std::vector<int64_t> map_begin;      // first bin of every map, + n_bins
@@ -110,7 +110,7 @@ struct bb_solver {
     bool row_owner = false;
     bool row_owner_built = false;        // created with the row-owner buffers (row_owner can be
                                          // switched off later: several maps, block steps)
-    bool block_steps = false;            // d_blk_scale set by bb_solver_set_block_steps
+    bool bin_steps = false;              // d_bin_scale set by bb_solver_set_bin_steps / _block_steps
     void *d_full = nullptr, *d_X2 = nullptr;
     int64_t full_ld = 0;
     double *d_ro_part = nullptr;   // 2 x ro_blocks per-workgroup stress sums (ping-pong)
@@ -565,7 +565,7 @@ void fill_reduce_params(bb_solver *s, ReduceParams<T> &p, int mode, double lr, d
     p.stress_slot = s->d_stress_slot;
     p.n_slots = s->n_slots;
     // (scale 1 is a plain sum -- the matvec, the spectral start's products: never scaled)
-    p.blk_scale = scale == 1.0 ? nullptr : (const T *)s->d_blk_scale;
+    p.bin_scale = scale == 1.0 ? nullptr : (const T *)s->d_bin_scale;
     p.map_ptr = s->d_map_ptr;
     p.map_idx = s->d_map_idx;
     p.n_maps = s->n_maps;
@@ -699,6 +699,20 @@ int set_wish_dense_t(bb_solver *s, const double *host, int64_t ld, int kind, dou
         rc = bb::fail(BB_ERR_HIP, std::string("set_wish_dense: ") + hipGetErrorString(e));
     hipFree(stage);
     return rc;
+}
+
+// n_pad factors (float64 on the host) -> d_bin_scale in the solver's type.
+int upload_bin_scale(bb_solver *s, const double *padded) {
+    const int64_t n = s->L.n_pad, es = bb::elem_size(s->dtype);
+    std::vector<char> host((size_t)(n * es));
+    for (int64_t i = 0; i < n; ++i) {
+        if (s->dtype == BB_F32) ((float *)host.data())[i] = (float)padded[i];
+        else ((double *)host.data())[i] = padded[i];
+    }
+    BB_HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (!s->d_bin_scale) BB_TRY(dev_alloc((char **)&s->d_bin_scale, n * es));
+    BB_HIP_CHECK(hipMemcpy(s->d_bin_scale, host.data(), host.size(), hipMemcpyHostToDevice));
+    return BB_OK;
 }
 
 // Row-owner path: rebuild both triangles from the freshly packed units.
@@ -908,7 +922,7 @@ int bb_solver_destroy(bb_solver *s) {
     hipFree(s->d_peer_counter);
     for (hipEvent_t e : s->ev) hipEventDestroy(e);
     hipFree(s->d_arena);
-    hipFree(s->d_blk_scale);
+    hipFree(s->d_bin_scale);
     hipFree(s->d_map_ptr);
     hipFree(s->d_map_idx);
     hipFree(s->d_map_scalar);
@@ -978,15 +992,10 @@ int bb_solver_set_maps(bb_solver *s, int n_maps, const int64_t *bin_begin, const
     for (size_t t = 0; t < s->tile_I.size(); ++t)
         BB_REQUIRE(map_of_block[(size_t)s->tile_I[t]] == map_of_block[(size_t)s->tile_J[t]],
                    "bb_solver_set_maps: a tile of the solver's list joins two maps");
-    // per block: the map's step; per map: its stress partials (wave w's own, index w, belongs
+    // per bin: its map's step; per map: its stress partials (wave w's own, index w, belongs
     // to the strip the wave ends in; slot q's, index n_waves + q, to the slot's strip)
-    const int64_t es = bb::elem_size(s->dtype);
-    std::vector<char> scale((size_t)(nb * es));
-    for (int64_t b = 0; b < nb; ++b) {
-        const double v = lr_scale[map_of_block[(size_t)b]];
-        if (s->dtype == BB_F32) ((float *)scale.data())[b] = (float)v;
-        else ((double *)scale.data())[b] = v;
-    }
+    std::vector<double> scale((size_t)s->L.n_pad);
+    for (int64_t i = 0; i < s->L.n_pad; ++i) scale[(size_t)i] = lr_scale[map_of_block[(size_t)(i / vw)]];
     std::vector<std::vector<int>> lists((size_t)n_maps);
     for (int w = 0; w < s->n_waves; ++w)
         if (s->wave_last_strip[(size_t)w] >= 0)
@@ -999,16 +1008,15 @@ int bb_solver_set_maps(bb_solver *s, int n_maps, const int64_t *bin_begin, const
         ptr.push_back((int)idx.size());
     }
     if (idx.empty()) idx.push_back(0);
-    hipFree(s->d_blk_scale); hipFree(s->d_map_ptr); hipFree(s->d_map_idx); hipFree(s->d_map_scalar);
-    s->d_blk_scale = nullptr; s->d_map_ptr = s->d_map_idx = nullptr; s->d_map_scalar = nullptr;
-    s->block_steps = false;        // (the maps' steps replace a bb_solver_set_block_steps)
+    hipFree(s->d_bin_scale); hipFree(s->d_map_ptr); hipFree(s->d_map_idx); hipFree(s->d_map_scalar);
+    s->d_bin_scale = nullptr; s->d_map_ptr = s->d_map_idx = nullptr; s->d_map_scalar = nullptr;
+    s->bin_steps = false;          // (the maps' steps replace a bb_solver_set_bin_steps)
     s->n_maps = 1;                 // (what holds if an allocation below fails: one map, no tables)
     s->map_begin.clear();
-    BB_TRY(dev_alloc((char **)&s->d_blk_scale, nb * es));
+    BB_TRY(upload_bin_scale(s, scale.data()));
     BB_TRY(dev_alloc(&s->d_map_ptr, (int64_t)ptr.size()));
     BB_TRY(dev_alloc(&s->d_map_idx, (int64_t)idx.size()));
     BB_TRY(dev_alloc(&s->d_map_scalar, n_maps));
-    BB_HIP_CHECK(hipMemcpy(s->d_blk_scale, scale.data(), scale.size(), hipMemcpyHostToDevice));
     BB_HIP_CHECK(hipMemcpy(s->d_map_ptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
     BB_HIP_CHECK(hipMemcpy(s->d_map_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
     // (a map that is never set carries no constraint)
@@ -1022,40 +1030,72 @@ int bb_solver_set_maps(bb_solver *s, int n_maps, const int64_t *bin_begin, const
     return BB_OK;
 }
 
-int bb_solver_set_block_steps(bb_solver *s, const double *scale, int64_t n_blocks) {
-    BB_REQUIRE(s != nullptr, "bb_solver_set_block_steps: solver is NULL");
+int bb_solver_set_bin_steps(bb_solver *s, const double *scale, int64_t n_bins) {
+    BB_REQUIRE(s != nullptr, "bb_solver_set_bin_steps: solver is NULL");
     if (s->n_maps > 1)
-        return bb::fail(BB_ERR_STATE, "bb_solver_set_block_steps: a solver of several maps has its "
+        return bb::fail(BB_ERR_STATE, "bb_solver_set_bin_steps: a solver of several maps has its "
                                       "steps from bb_solver_set_maps");
     if (s->grad_pending)
-        return bb::fail(BB_ERR_STATE, "bb_solver_set_block_steps: a bb_solver_grad is pending");
+        return bb::fail(BB_ERR_STATE, "bb_solver_set_bin_steps: a bb_solver_grad is pending");
     BB_TRY(bb::enter_device(s->device));
     if (scale == nullptr) {                       // back to one step for all
         BB_HIP_CHECK(hipStreamSynchronize(s->stream));
-        hipFree(s->d_blk_scale);
-        s->d_blk_scale = nullptr;
-        s->block_steps = false;
+        hipFree(s->d_bin_scale);
+        s->d_bin_scale = nullptr;
+        s->bin_steps = false;
         if (s->row_owner_built && !s->row_owner) {
             s->row_owner = true;
             if (s->have_wish) BB_TRY(refresh_full(s));
         }
         return BB_OK;
     }
-    const int64_t nb = s->L.n_blocks, es = bb::elem_size(s->dtype);
-    BB_REQUIRE(n_blocks == nb, "bb_solver_set_block_steps: one factor per block of the layout "
-                               "(bb_solver_layout: n_blocks)");
-    std::vector<char> host((size_t)(nb * es));
-    for (int64_t b = 0; b < nb; ++b) {
-        BB_REQUIRE(std::isfinite(scale[b]) && scale[b] > 0.0,
-                   "bb_solver_set_block_steps: factors must be finite and positive");
-        if (s->dtype == BB_F32) ((float *)host.data())[b] = (float)scale[b];
-        else ((double *)host.data())[b] = scale[b];
+    BB_REQUIRE(n_bins == s->L.n_bins, "bb_solver_set_bin_steps: one factor per bin");
+    std::vector<double> padded((size_t)s->L.n_pad, 1.0);
+    for (int64_t i = 0; i < n_bins; ++i) {
+        BB_REQUIRE(std::isfinite(scale[i]) && scale[i] > 0.0,
+                   "bb_solver_set_bin_steps: factors must be finite and positive");
+        padded[(size_t)i] = scale[i];
     }
+    BB_TRY(upload_bin_scale(s, padded.data()));
+    s->bin_steps = true;
+    s->row_owner = false;          // the sweep: its reduce knows the factors
+    return BB_OK;
+}
+
+int bb_solver_set_block_steps(bb_solver *s, const double *scale, int64_t n_blocks) {
+    BB_REQUIRE(s != nullptr, "bb_solver_set_block_steps: solver is NULL");
+    if (scale == nullptr) return bb_solver_set_bin_steps(s, nullptr, 0);
+    BB_REQUIRE(n_blocks == s->L.n_blocks, "bb_solver_set_block_steps: one factor per block of the "
+                                          "layout (bb_solver_layout: n_blocks)");
+    std::vector<double> per_bin((size_t)s->L.n_bins);
+    for (int64_t i = 0; i < s->L.n_bins; ++i) per_bin[(size_t)i] = scale[i / s->L.vw];
+    return bb_solver_set_bin_steps(s, per_bin.data(), s->L.n_bins);
+}
+
+int bb_solver_degrees(bb_solver *s, int64_t *degree, int64_t n_bins) {
+    BB_REQUIRE(s != nullptr && degree != nullptr, "bb_solver_degrees: NULL argument");
+    BB_REQUIRE(n_bins == s->L.n_bins, "bb_solver_degrees: one count per bin");
+    if (!s->have_wish) return bb::fail(BB_ERR_STATE, "bb_solver_degrees: no wish distances set");
+    BB_TRY(bb::enter_device(s->device));
+    bb::DevBuf buf;
+    if (buf.alloc((size_t)s->L.n_pad * sizeof(int)) != hipSuccess)
+        return bb::fail(BB_ERR_NOMEM, "bb_solver_degrees: out of device memory");
+    BB_HIP_CHECK(hipMemsetAsync(buf.p, 0, (size_t)s->L.n_pad * sizeof(int), s->stream));
+    if (s->n_local > 0) {
+#define BB_DEG(TT, WW)                                                                            \
+    BB_HIP_CHECK(bb::launch(unit_degrees_kernel<TT, WW>,                                           \
+                            dim3((unsigned)((s->n_local + kDegUnits - 1) / kDegUnits)), dim3(256), 0, \
+                            s->stream, (const TT *)s->d_units, s->d_udesc, s->n_local, s->L.n_bins,  \
+                            (int *)buf.p))
+        if (s->dtype == BB_F32) BB_DEG(float, true);
+        else if (s->wide) BB_DEG(double, true);
+        else BB_DEG(double, false);
+#undef BB_DEG
+    }
+    std::vector<int> host((size_t)n_bins);
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
-    if (!s->d_blk_scale) BB_TRY(dev_alloc((char **)&s->d_blk_scale, nb * es));
-    BB_HIP_CHECK(hipMemcpy(s->d_blk_scale, host.data(), host.size(), hipMemcpyHostToDevice));
-    s->block_steps = true;
-    s->row_owner = false;          // the sweep: its reduce knows the blocks
+    BB_HIP_CHECK(hipMemcpy(host.data(), buf.p, (size_t)n_bins * sizeof(int), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n_bins; ++i) degree[i] = host[(size_t)i];
     return BB_OK;
 }
 

@@ -1241,14 +1241,14 @@ struct ReduceParams {
     T lr;
     const double *__restrict__ stress_slot;  // per private column slot (see the sweep)
     int n_slots;
-    // a step per block (bb_solver_set_block_steps; bb_solver_set_maps: the map's): the
-    // gradient of block b leaves the reduce as blk_scale[b] * g -- into the update, the
+    // a step per bin (bb_solver_set_bin_steps / _block_steps; bb_solver_set_maps: the map's):
+    // the gradient of bin i leaves the reduce as bin_scale[i] * g_i -- into the update, the
     // exchange buffer or the peers' arenas alike, so every rank and every later kernel steps
     // with the one uniform lr (nullptr for a plain sum: the matvec).  Several maps
     // (world = 1): the stress is folded per map -- map m's partials are
     // map_idx[map_ptr[m] .. map_ptr[m + 1]) (index < n_waves: stresspart, else stress_slot) --
     // into stress_out[m].  n_maps <= 1: one map, every partial, stress_out[0].
-    const T *__restrict__ blk_scale;
+    const T *__restrict__ bin_scale;        // n_pad factors (element o of X belongs to bin o / 3)
     const int *__restrict__ map_ptr;
     const int *__restrict__ map_idx;
     int n_maps;
@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(kRedWG) void reduce_kernel(ReduceParams<T> p) {
         if (p.mode == kReducePartial) {
             p.part_out[o] = acc;
         } else {
-            const T g = p.blk_scale ? p.blk_scale[b] * (p.scale * acc) : p.scale * acc;
+            const T g = p.bin_scale ? p.bin_scale[o / 3] * (p.scale * acc) : p.scale * acc;
             if (p.mode == kReduceApply) {
                 // SPEC 2.4: V <- mu V - lr g ; X <- X + V   (mu = 0: X -= lr g)
                 const T v = p.mu * p.V[o] - p.lr * g;
@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(128 * S) void reduce_sliced_kernel(ReduceParams<T> 
             T tot = meet[0][el];
 #pragma unroll
             for (int q = 1; q < S; ++q) tot += meet[q][el];
-            const T g = p.blk_scale ? p.blk_scale[b] * (p.scale * tot) : p.scale * tot;
+            const T g = p.bin_scale ? p.bin_scale[o / 3] * (p.scale * tot) : p.scale * tot;
             if (p.mode == kReduceApply) {
                 // SPEC 2.4: V <- mu V - lr g ; X <- X + V   (mu = 0: X -= lr g)
                 const T v = p.mu * vo - p.lr * g;
@@ -1671,7 +1671,7 @@ __global__ __launch_bounds__(128 * S) void reduce_exchange_kernel(
         T tot = meet[0][el];
 #pragma unroll
         for (int q = 1; q < S; ++q) tot += meet[q][el];
-        const T mine = peer_sendable(p.blk_scale ? p.blk_scale[b] * (p.scale * tot) : p.scale * tot);
+        const T mine = peer_sendable(p.bin_scale ? p.bin_scale[o / 3] * (p.scale * tot) : p.scale * tot);
         for (int q = 0; q < R; ++q)
             __hip_atomic_store(xt->dst[q] + o, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         T g;
@@ -2207,6 +2207,57 @@ __global__ __launch_bounds__(256) void units_to_full_kernel(const T *__restrict_
             full[j * ld + i] = v;
         }
     }
+}
+
+// Per bin: how many of this rank's stored pairs constrain it (delta > 0) -- the degrees a step
+// per bin is made from (bb_solver_degrees; once per map, not per iteration).  A workgroup takes
+// kDegUnits consecutive units: a row's count is a ballot per wave (one atomic per wave and
+// row), a column's is kept by the thread that owns the column for as long as the units stay
+// in one tile column (one atomic per column and run of units).
+constexpr int kDegUnits = 32;
+template <typename T, bool W>
+__global__ __launch_bounds__(256) void unit_degrees_kernel(const T *__restrict__ units,
+                                                           const int2 *__restrict__ udesc,
+                                                           int64_t n_local, int64_t n_bins,
+                                                           int *__restrict__ deg) {
+    constexpr int VW = Lay<T, W>::VW, RPU = Lay<T, W>::RPU, CPT = (VW + 255) / 256;
+    const int lane = threadIdx.x & 63;
+    const int64_t u0 = (int64_t)blockIdx.x * kDegUnits;
+    const int64_t u1 = u0 + kDegUnits < n_local ? u0 + kDegUnits : n_local;
+    int col[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) col[k] = 0;
+    int j0 = udesc[u0].y;
+    auto flush = [&]() {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int c = (int)threadIdx.x + 256 * k;
+            if (c < VW && col[k] > 0) atomicAdd(deg + j0 + c, col[k]);
+            col[k] = 0;
+        }
+    };
+    for (int64_t ul = u0; ul < u1; ++ul) {
+        const int2 dsc = udesc[ul];
+        if (dsc.y != j0) {                              // (uniform: every thread reads the same word)
+            flush();
+            j0 = dsc.y;
+        }
+        const T *in = units + ul * (RPU * VW);
+        for (int r = 0; r < RPU; ++r) {
+            const int64_t i = (int64_t)dsc.x + r;
+            int row = 0;
+#pragma unroll
+            for (int k = 0; k < CPT; ++k) {
+                const int c = (int)threadIdx.x + 256 * k;
+                const int64_t j = (int64_t)dsc.y + c;
+                const bool on = c < VW && j > i && j < n_bins && in[r * VW + c] > T(0);
+                col[k] += on ? 1 : 0;
+                row += __popcll(__ballot(on));
+            }
+            if (lane == 0 && row > 0) atomicAdd(deg + i, row);
+        }
+    }
+    flush();
 }
 
 // Measurement only: the same waves read the same units with the same rolling

@@ -202,6 +202,26 @@ class HipEngine(object):
         _lib.check(self._lib.bb_solver_set_block_steps(self._h, _lib.as_f64_ptr(sc), sc.shape[0]),
                    "bb_solver_set_block_steps")
 
+    def set_bin_steps(self, scale):
+        """A step per bin (`bb_solver_set_bin_steps`): bin i moves by lr * scale[i] * g_i;
+        None = one step for all again."""
+        if scale is None:
+            _lib.check(self._lib.bb_solver_set_bin_steps(self._h, None, 0), "bb_solver_set_bin_steps")
+            return
+        sc = numpy.ascontiguousarray(scale, dtype=numpy.float64)
+        if sc.ndim != 1:
+            raise ValueError("scale must be one factor per bin")
+        _lib.check(self._lib.bb_solver_set_bin_steps(self._h, _lib.as_f64_ptr(sc), sc.shape[0]),
+                   "bb_solver_set_bin_steps")
+
+    def degrees(self):
+        """Per bin, the number of this rank's stored pairs that constrain it (delta > 0):
+        `bb_solver_degrees`, one pass over the resident units."""
+        out = numpy.zeros(self.n_bins, dtype=numpy.int64)
+        _lib.check(self._lib.bb_solver_degrees(self._h, out.ctypes.data_as(_lib.p_i64), out.shape[0]),
+                   "bb_solver_degrees")
+        return out
+
     def stress_maps(self):
         out = numpy.empty(getattr(self, "n_maps", 1), dtype=numpy.float64)
         _lib.check(self._lib.bb_solver_stress_maps(self._h, _lib.as_f64_ptr(out), out.shape[0]),
@@ -600,6 +620,34 @@ def block_step_factors(n_bins, tiles, dtype):
     return 1.0 / (2.0 * top), numpy.where(deg > 0, top / numpy.maximum(deg, 1), 1.0)
 
 
+def degree_step_factors(degree):
+    """(lr, scale) of SPEC 2.4.1 from the bins' degrees (number of constraining pairs):
+    lr = 1 / (2 (D + 1)), D the largest degree, and scale[i] = (D + 1) / (degree[i] + 1), so
+    that bin i steps by 1 / (2 (degree[i] + 1)) -- for a complete map of n bins exactly SPEC
+    2.4's 1 / (2 n).  scale is None when all bins have the same degree."""
+    deg = numpy.asarray(degree, dtype=numpy.int64)
+    top = int(deg.max()) if deg.size else 0
+    lr = 1.0 / (2.0 * (top + 1))
+    if deg.size == 0 or int(deg.min()) == top:
+        return lr, None
+    return lr, (top + 1.0) / (deg + 1.0)
+
+
+def _sum_over_ranks(counts, eng, world):
+    """Element-wise sum of an int64 host array over the ranks (world 1: the array)."""
+    if world <= 1:
+        return counts
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(numpy.ascontiguousarray(counts, dtype=numpy.int64))
+    if dist.get_backend() == "nccl":
+        t = t.to(torch.device("cuda", getattr(eng, "device", 0)))
+        dist.all_reduce(t)
+        return t.cpu().numpy()
+    dist.all_reduce(t)
+    return t.numpy()
+
+
 def allreduce_exchange(t):
     """Sum a device-resident exchange tensor over all ranks, in place: one
     all-reduce of 3*n_pad+2 elements (backend nccl = RCCL, over xGMI)."""
@@ -667,12 +715,15 @@ class StructureSolver(object):
     init : 'random' or 'spectral'
         Start used when `fit()` gets no `init=` array: seeded standard normal, or
         classical MDS computed on the device (`spectral_init`).
-    block_steps : bool
-        Blocked-sparse input only (scipy.sparse matrices, `fit_triples`): a step per block of
-        the tile layout, 1 / (2 degree[b]) with degree[b] the block's number of stored
-        partner bins, instead of one step for all (`lr='auto'`: 1 / (2 N); SPEC 2.4.1).  A
-        whole-genome map converges in about a third of the iterations; a float `lr` is then
-        the step of the block with the most partners.  Dense input: no effect.
+    degree_steps : bool
+        A step per bin from the map itself (SPEC 2.4.1): bin i steps by 1 / (2 (deg_i + 1)),
+        deg_i = the number of pairs that constrain it (counted on the device, summed over
+        the ranks), instead of one step for all (`lr='auto'`: 1 / (2 N), the step of a
+        COMPLETE map).  For incomplete maps -- blocked-sparse input, a whole genome whose
+        chromosomes differ in size, real maps whose long-range pairs have no contact -- that
+        is each bin's own Guttman-like step: a genome-like map converges in about a third
+        of the iterations.  A float `lr` is then the step of the bin with the most partners.
+        A complete map: no effect.
     spectral_iter, spectral_tol : int, float
         The spectral start's block power iteration makes at most `spectral_iter` products
         and ends once B V lies within `spectral_tol` (relative) of span(V); 0 = always
@@ -707,7 +758,7 @@ class StructureSolver(object):
     def __init__(self, n_iter=100, lr="auto", dtype="float32", alpha=3.0, kind="counts",
                  seed=0, device=None, distributed=None, engine=None, momentum=0.0,
                  init="random", tol=None, check_every=10, spectral_iter=40, spectral_tol=1e-3,
-                 block_steps=False):
+                 degree_steps=False):
         if dtype not in _DTYPES:
             raise ValueError("dtype must be 'float32' or 'float64'")
         if kind not in _KINDS:
@@ -735,7 +786,7 @@ class StructureSolver(object):
         if int(spectral_iter) < 0 or not 0.0 <= float(spectral_tol) < 1.0:
             raise ValueError("need spectral_iter >= 0 and 0 <= spectral_tol < 1")
         self.spectral_iter, self.spectral_tol = int(spectral_iter), float(spectral_tol)
-        self.block_steps = bool(block_steps)
+        self.degree_steps = bool(degree_steps)
         self.n_iter, self.lr, self.dtype, self.alpha, self.kind, self.seed = (
             int(n_iter), lr, dtype, float(alpha), kind, int(seed))
         self.device, self.distributed = device, distributed
@@ -788,16 +839,9 @@ class StructureSolver(object):
             tiles = tiles_from_entries(n, rows, cols, self.dtype)
         elif triples:
             tiles = matrix.tiles(n, self.dtype)
-        scale = None
-        if self.block_steps and tiles is not None:
-            lr_top, scale = block_step_factors(n, tiles, self.dtype)
-            if self.lr == "auto":
-                lr = lr_top
         eng = self._engine_factory(n, self.dtype, rank=rank, world=world,
                                    device=self._pick_device(world), tiles=tiles)
         try:
-            if scale is not None:
-                eng.set_block_steps(scale)
             if resident:
                 dev = matrix._resident()
                 if dev.device == eng.device:
@@ -812,6 +856,12 @@ class StructureSolver(object):
                 eng.set_wish_sparse(rows, cols, vals, self.kind, self.alpha, KRnorm, KRexpected)
             else:
                 eng.set_wish_dense(matrix, self.kind, self.alpha)
+            if self.degree_steps:
+                lr_top, scale = degree_step_factors(_sum_over_ranks(eng.degrees(), eng, world))
+                if self.lr == "auto":
+                    lr = lr_top
+                if scale is not None:
+                    eng.set_bin_steps(scale)
             on_device = False
             if init is None:
                 # 'spectral'.  The whole block power iteration stays on the device -- on one

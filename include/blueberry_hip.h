@@ -151,19 +151,31 @@ BB_API int bb_solver_set_maps(bb_solver *s, int n_maps, const int64_t *bin_begin
 BB_API int bb_solver_set_wish_dense_block(bb_solver *s, const double *host, int64_t ld,
                                           int64_t n_sub, int64_t bin_offset, int kind, double alpha);
 BB_API int bb_solver_stress_maps(bb_solver *s, double *stress, int n_maps);
-/* A STEP PER BLOCK of the layout (bb_solver_layout: n_blocks blocks of vw bins): bin i moves by
- * lr * scale[i / vw] * g_i.  For a blocked-sparse map the bins do not all have the same number
- * of stored partners -- the whole genome at 10 kb: 24,926 for a bin of chr1, 4,813 for one of
- * chr21 -- and the one step the largest degree allows, 1 / (2 max_degree), is five times too
- * short for the small chromosomes; with scale[b] = max_degree / degree[b] every block takes
- * the step its own degree allows (SPEC 2.4.1; on a genome-like tile list 1e-3 of the start's
- * stress in a third of the iterations).  The gradient of block b is scaled where it leaves
- * the reduce -- into the update, the exchange buffer (bb_solver_grad then holds scale * g)
- * or the peers' arenas -- so it works on any number of ranks with every exchange; every rank
- * passes the same factors.  scale = NULL: one step for all again.  Maps of at most 4,096 bins
- * on one rank iterate with the unit sweep while factors are set.  BB_ERR_STATE for a solver
- * of several maps (bb_solver_set_maps gives each map its step) and while a bb_solver_grad is
- * pending.  No counterpart in the reference (it has no solver). */
+/* A STEP PER BIN: bin i moves by lr * scale[i] * g_i.  SPEC 2.4's step 1 / (2 N) is the
+ * Guttman transform of a COMPLETE map; in an incomplete one the bins do not all have N - 1
+ * partners -- the whole genome at 10 kb as blocks: 24,926 for a bin of chr1, 4,813 for one of
+ * chr21; inside a real chromosome's block most long-range pairs have no contact at all -- and
+ * the one step the largest degree allows is many times too short for the rest.  With
+ * scale[i] = (D + 1) / (degree[i] + 1), D the largest degree, and lr = 1 / (2 (D + 1)) every
+ * bin takes the step 1 / (2 (degree[i] + 1)) its own number of partners allows (SPEC 2.4.1:
+ * still a descent step; on a genome-like tile list 1e-3 of the start's stress in a third of
+ * the iterations).
+ *   bb_solver_degrees          per bin, how many of THIS rank's stored pairs constrain it
+ *                              (delta > 0): one pass over the resident units; world > 1: the
+ *                              caller sums the counts over the ranks
+ *   bb_solver_set_bin_steps    the factors, one per bin (finite, > 0); NULL: one step for all
+ *   bb_solver_set_block_steps  the same from one factor per block of the layout
+ *                              (bb_solver_layout: n_blocks blocks of vw bins) -- what a tile
+ *                              list alone gives, without a pass over the data
+ * The gradient of bin i is scaled where it leaves the reduce -- into the update, the
+ * exchange buffer (bb_solver_grad then holds scale * g) or the peers' arenas -- so it works
+ * on any number of ranks with every exchange; every rank passes the same factors.  Maps of at
+ * most 4,096 bins on one rank iterate with the unit sweep while factors are set.
+ * BB_ERR_STATE for a solver of several maps (bb_solver_set_maps gives each map its step)
+ * and while a bb_solver_grad is pending.  No counterpart in the reference (it has no solver;
+ * SURVEY.md 0). */
+BB_API int bb_solver_degrees(bb_solver *s, int64_t *degree, int64_t n_bins);
+BB_API int bb_solver_set_bin_steps(bb_solver *s, const double *scale, int64_t n_bins);
 BB_API int bb_solver_set_block_steps(bb_solver *s, const double *scale, int64_t n_blocks);
 /* Blocked-sparse input: nnz entries (rows[k], cols[k], vals[k]) of the symmetric
  * matrix, either triangle; an unordered pair that occurs more than once keeps its

@@ -158,7 +158,7 @@ BBO_API int bbo_solve_momentum_mt(const double *wish, long n, long ld, double *X
 static int solve_gen_impl(const double *xstar, long n, const int *tile_I, const int *tile_J,
                           long n_tiles, long vw, double *X, long iters, double lr, double mu,
                           int eps2_kind, int delta_f32, double flush, double *stress_hist,
-                          int threads, const double *blk_scale)
+                          int threads, const double *bin_scale)
 {
     const double eps2 = eps2_kind ? BBO_EPS2_F64 : BBO_EPS2_F32;
     if (threads < 1) threads = 1;
@@ -204,7 +204,7 @@ static int solve_gen_impl(const double *xstar, long n, const int *tile_I, const 
             for (long e = 0; e < 3 * n; e++) {
                 double a = 0.0;
                 for (int q = 0; q < T; q++) a += G[3 * (size_t)n * (size_t)q + e];
-                if (blk_scale) a *= blk_scale[(e / 3) / vw];
+                if (bin_scale) a *= bin_scale[e / 3];
                 V[e] = mu * V[e] - lr * a;
                 X[e] += V[e];
             }
@@ -231,15 +231,15 @@ BBO_API int bbo_solve_gen_mt(const double *xstar, long n, const int *tile_I, con
                           delta_f32, flush, stress_hist, threads, NULL);
 }
 
-/* The same with a step per block of vw bins (bb_solver_set_block_steps, docs/SPEC.md 2.4.1):
- * bin i moves by lr * blk_scale[i / vw] * g_i -- the gradient is scaled where it leaves the
- * sum, then the uniform step and the momentum apply, as in the kernels. */
+/* The same with a step per bin (bb_solver_set_bin_steps, docs/SPEC.md 2.4.1): bin i moves
+ * by lr * bin_scale[i] * g_i -- the gradient is scaled where it leaves the sum, then the
+ * uniform step and the momentum apply, as in the kernels. */
 BBO_API int bbo_solve_gen_steps_mt(const double *xstar, long n, const int *tile_I,
                                    const int *tile_J, long n_tiles, long vw, double *X, long iters,
                                    double lr, double mu, int eps2_kind, int delta_f32,
                                    double flush, double *stress_hist, int threads,
-                                   const double *blk_scale)
+                                   const double *bin_scale)
 {
     return solve_gen_impl(xstar, n, tile_I, tile_J, n_tiles, vw, X, iters, lr, mu, eps2_kind,
-                          delta_f32, flush, stress_hist, threads, blk_scale);
+                          delta_f32, flush, stress_hist, threads, bin_scale);
 }

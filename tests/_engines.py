@@ -45,7 +45,26 @@ class OracleEngine(object):
         self.mu = float(mu)
 
     def set_block_steps(self, scale):
-        self.blk_scale = None if scale is None else numpy.asarray(scale, dtype=numpy.float64)
+        self.set_bin_steps(None if scale is None else
+                           numpy.repeat(numpy.asarray(scale, dtype=numpy.float64), self.info.vw)[:self.n_bins])
+
+    def set_bin_steps(self, scale):
+        self.bin_scale = None if scale is None else numpy.asarray(scale, dtype=numpy.float64)
+
+    def _own_pairs(self):
+        """Mask of the pairs i < j this rank's units hold."""
+        n, vw, upt = self.n_bins, self.info.vw, self.info.units_per_tile
+        rpu = vw // upt
+        own = numpy.zeros((n, n), dtype=bool)
+        for u in range(self.u_begin, self.u_end):
+            t, sub = divmod(u, upt)
+            i0, j0 = int(self.ti[t]) * vw + sub * rpu, int(self.tj[t]) * vw
+            own[i0:min(i0 + rpu, n), j0:min(j0 + vw, n)] = True
+        return numpy.triu(own, 1)
+
+    def degrees(self):
+        on = self._own_pairs() & (self.w > 0)
+        return (on.sum(axis=0) + on.sum(axis=1)).astype(numpy.int64)
 
     def set_coords(self, x0):
         self.X = numpy.ascontiguousarray(x0, dtype=numpy.float64).copy()
@@ -59,8 +78,8 @@ class OracleEngine(object):
         s, g = self.oracle.stress_grad_units(self.w, self.X, self.ti, self.tj,
                                              self.info.units_per_tile, self.info.vw,
                                              self.u_begin, self.u_end)
-        if getattr(self, "blk_scale", None) is not None:     # scaled where it leaves the sum
-            g = g * numpy.repeat(self.blk_scale, self.info.vw)[:self.n_bins, None]
+        if getattr(self, "bin_scale", None) is not None:     # scaled where it leaves the sum
+            g = g * self.bin_scale[:, None]
         self.exch[:] = 0
         self.exch[:3 * self.n_bins] = g.ravel()
         self.exch[-2] = s
@@ -124,15 +143,7 @@ class OracleEngine(object):
 
     def matvec_sq(self, x):
         """(D o D) @ x restricted to the pairs this rank's units own (numpy)."""
-        n, vw, upt = self.n_bins, self.info.vw, self.info.units_per_tile
-        rpu = vw // upt
-        own = numpy.zeros((n, n), dtype=bool)
-        for u in range(self.u_begin, self.u_end):
-            t, sub = divmod(u, upt)
-            i0, j0 = int(self.ti[t]) * vw + sub * rpu, int(self.tj[t]) * vw
-            own[i0:min(i0 + rpu, n), j0:min(j0 + vw, n)] = True
-        own = numpy.triu(own, 1)
-        a = numpy.where(own, self.w * self.w, 0.0)
+        a = numpy.where(self._own_pairs(), self.w * self.w, 0.0)
         x = numpy.asarray(x, dtype=numpy.float64)
         return a @ x + a.T @ x
 

@@ -215,12 +215,13 @@ def dense_tiles(n, vw=512):
 
 
 def solve_gen_mt(xstar, X0, iters, lr, threads, tiles=None, vw=512, mu=0.0, f64=True,
-                 delta_f32=None, blk_scale=None):
+                 delta_f32=None, blk_scale=None, bin_scale=None):
     """The solver loop with delta_ij = |x*_i - x*_j| formed on the fly over a tile list
     (None: the dense upper triangle) -- no matrix in memory, so N = 50,000 dense and
     BASELINE config 5 (N = 309,568 block-sparse) run on the host.  delta_f32 (default:
-    not f64) rounds delta to float exactly as the device's fp32 pack does.  blk_scale: a
-    step factor per block of vw bins (bb_solver_set_block_steps)."""
+    not f64) rounds delta to float exactly as the device's fp32 pack does.  bin_scale: a
+    step factor per bin (bb_solver_set_bin_steps); blk_scale: one per block of vw bins
+    (bb_solver_set_block_steps)."""
     lib = _load_mt()
     xs = numpy.ascontiguousarray(xstar, dtype=numpy.float64)
     X = numpy.ascontiguousarray(X0, dtype=numpy.float64).copy()
@@ -235,11 +236,14 @@ def solve_gen_mt(xstar, X0, iters, lr, threads, tiles=None, vw=512, mu=0.0, f64=
             ti.shape[0], int(vw), _p(X), int(iters), float(lr), float(mu),
             1 if f64 else 0, 1 if delta_f32 else 0,
             1e-30 if delta_f32 else 1e-290, _p(hist), int(threads))
-    if blk_scale is None:
+    if blk_scale is not None:
+        assert numpy.shape(blk_scale) == (-(-n // int(vw)),)
+        bin_scale = numpy.repeat(numpy.asarray(blk_scale, dtype=numpy.float64), int(vw))[:n]
+    if bin_scale is None:
         rc = lib.bbo_solve_gen_mt(*args)
     else:
-        sc = numpy.ascontiguousarray(blk_scale, dtype=numpy.float64)
-        assert sc.shape == (-(-n // int(vw)),)
+        sc = numpy.ascontiguousarray(bin_scale, dtype=numpy.float64)
+        assert sc.shape == (n,)
         rc = lib.bbo_solve_gen_steps_mt(*(args + (_p(sc),)))
     if rc != 0:
         raise MemoryError("bbo_solve_gen_mt: out of memory")

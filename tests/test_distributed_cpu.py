@@ -85,6 +85,80 @@ def test_sharded_solve_equals_single_process_oracle(oracle, world, dtype):
         assert numpy.array_equal(X, results[0][1]) and numpy.array_equal(hist, results[0][2])
 
 
+# ---- degree_steps on several ranks: the degrees are summed over the ranks ----------------
+def _degree_worker(rank, world, port, n, k, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import blueberry_amd as bb
+        from tests import _oracle
+        from tests._engines import OracleEngine
+        w, x0 = _holey_map(n)
+        s = bb.StructureSolver(n_iter=k, dtype="float64", kind="wish", engine=OracleEngine,
+                               degree_steps=True).fit(w, init=x0)
+        q.put((rank, s.structure_, s.stress_, s.lr_))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, traceback.format_exc(), None, None))
+
+
+def _holey_map(n):
+    """Two dense blocks of unequal size (5 : 1) joined by a narrow band."""
+    from tests import _oracle
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    i, j = numpy.indices((n, n))
+    cut = (5 * n) // 6
+    keep = ((i < cut) & (j < cut)) | ((i >= cut) & (j >= cut)) | (numpy.abs(i - j) <= 30)
+    return numpy.where(keep, w, 0.0), _oracle.noisy_init(xs)
+
+
+def test_degree_steps_on_two_ranks_equal_one_process(oracle):
+    """StructureSolver(degree_steps=True) on 2 gloo ranks: every rank counts the degrees of
+    its own units, the counts are summed over the ranks, every rank sets the same factors
+    and step; the result is the one-process run and the oracle loop with those factors."""
+    import torch.multiprocessing as mp
+    import blueberry_amd as bb
+    from blueberry_amd.solver import degree_step_factors
+    from tests._engines import OracleEngine
+    n, k, world = 600, 6, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_degree_worker, args=(r, world, port, n, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert not isinstance(r[1], str), r[1]
+    w, x0 = _holey_map(n)
+    deg = (w > 0).sum(axis=0)
+    lr, scale = degree_step_factors(deg)
+    assert scale.max() > 3.0
+    X, hist = x0.copy(), []
+    for _ in range(k):
+        s_, g = oracle.stress_grad(w, X)
+        X = X - lr * scale[:, None] * g
+        hist.append(s_)
+    one = bb.StructureSolver(n_iter=k, dtype="float64", kind="wish", engine=OracleEngine,
+                             distributed=False, degree_steps=True).fit(w, init=x0)
+    plain = bb.StructureSolver(n_iter=k, dtype="float64", kind="wish", engine=OracleEngine,
+                               distributed=False).fit(w, init=x0)
+    assert one.lr_ == lr and numpy.abs(one.stress_ / numpy.array(hist) - 1).max() < 1e-12
+    assert one.stress_[-1] < plain.stress_[-1]
+    for rank, Xr, hr, lr_r in results:
+        assert lr_r == lr
+        assert numpy.abs(hr / numpy.array(hist) - 1).max() < 1e-11
+        assert numpy.abs(Xr - X).max() < 1e-11 * numpy.abs(X).max()
+    assert numpy.array_equal(results[0][1], results[1][1])
+
+
 # ---- init='spectral' on several ranks: which form runs, and that the ranks agree --------
 def _spectral_worker(rank, world, port, n, fail_rank, q):
     """fit(init='spectral') on `world` gloo ranks with an engine that HAS a device-resident

@@ -1597,6 +1597,21 @@ def test_block_steps_small_maps_and_errors():
         hist.append(s_)
     assert numpy.abs(e.stress_history() / numpy.array(hist) - 1).max() < 1e-12
     assert _rel(e.get_coords(), X) < 1e-12
+    # one factor per bin: the primitive the block form expands into
+    per = numpy.random.default_rng(1).uniform(0.5, 1.5, n)
+    e.set_bin_steps(per)
+    e.set_coords(x0)
+    e.iterate(k, lr)
+    X, hist = x0.copy(), []
+    for _ in range(k):
+        s_, g = _oracle.load().stress_grad(w, X)
+        X = X - lr * per[:, None] * g
+        hist.append(s_)
+    assert numpy.abs(e.stress_history() / numpy.array(hist) - 1).max() < 1e-12
+    assert _rel(e.get_coords(), X) < 1e-12
+    assert numpy.array_equal(e.degrees(), numpy.full(n, n - 1))       # a complete map
+    with pytest.raises(ValueError, match="one factor per bin"):
+        e.set_bin_steps(numpy.ones(n + 1))
     e.set_block_steps(None)
     assert e.iteration_path()[0] == "row_owner"
     e.set_coords(x0)
@@ -1622,12 +1637,13 @@ def test_block_steps_small_maps_and_errors():
     e.close()
 
 
-def test_structure_solver_block_steps_on_sparse_and_triples():
-    """StructureSolver(block_steps=True): scipy.sparse input and fit_triples take a step per
-    block (lr='auto' -> 1 / (2 max_degree)); equal to driving the engine by hand, fewer
-    iterations to a given stress than one step for all, and no effect on dense input."""
+def test_structure_solver_degree_steps():
+    """StructureSolver(degree_steps=True): a step per bin from the map's own degrees, counted
+    on the device (bb_solver_degrees) -- scipy.sparse input, fit_triples and a dense matrix
+    with holes; equal to driving the engine by hand, far lower stress after the same number
+    of iterations than one step for all, and no effect on a complete map."""
     import scipy.sparse
-    from blueberry_amd.solver import block_step_factors, tiles_from_entries
+    from blueberry_amd.solver import degree_step_factors, tiles_from_entries
     sizes = [1500, 700, 300]
     n = sum(sizes)
     xs = _oracle.random_walk(n, seed=7)
@@ -1641,28 +1657,45 @@ def test_structure_solver_block_steps_on_sparse_and_triples():
     wm = numpy.where(mask | band, w, 0.0)
     sp = scipy.sparse.coo_matrix(numpy.triu(wm, 1))
     x0 = _oracle.noisy_init(xs, seed=8)
-    a = bb.StructureSolver(n_iter=40, dtype="float64", kind="wish", block_steps=True).fit(sp, init=x0)
+    a = bb.StructureSolver(n_iter=40, dtype="float64", kind="wish", degree_steps=True).fit(sp, init=x0)
     b = bb.StructureSolver(n_iter=40, dtype="float64", kind="wish").fit(sp, init=x0)
     tiles = tiles_from_entries(n, sp.row, sp.col, "float64")
-    lr, scale = block_step_factors(n, tiles, "float64")
-    assert a.lr_ == lr and b.lr_ == 1.0 / (2 * n)
+    deg_ref = (wm > 0).sum(axis=0) - (numpy.diag(wm) > 0)
+    lr, scale = degree_step_factors(deg_ref)
+    assert a.lr_ == lr == 1.0 / (2 * (deg_ref.max() + 1)) and b.lr_ == 1.0 / (2 * n)
+    assert scale.min() == 1.0 and scale.max() > 3.0
     e = HipEngine(n, "float64", tiles=tiles)
-    e.set_block_steps(scale)
     e.set_wish_sparse(sp.row.astype(numpy.int64), sp.col.astype(numpy.int64), sp.data, "wish", 3.0)
+    assert numpy.array_equal(e.degrees(), deg_ref)             # counted on the device
+    e.set_bin_steps(scale)
     e.set_coords(x0)
     e.iterate(40, lr)
     assert numpy.array_equal(e.stress_history(), a.stress_) and numpy.array_equal(e.get_coords(), a.structure_)
+    # ... which is the oracle's loop with the same factors
+    X, V, hist = x0.copy(), numpy.zeros_like(x0), []
+    for _ in range(5):
+        s_, g = _oracle.load().stress_grad(wm, X)
+        X = X - lr * scale[:, None] * g
+        hist.append(s_)
+    assert numpy.abs(a.stress_[:5] / numpy.array(hist) - 1).max() < 1e-12
     e.close()
-    assert a.stress_[-1] < 0.2 * b.stress_[-1]
+    assert (numpy.diff(a.stress_) <= 0).all() and a.stress_[-1] < 0.2 * b.stress_[-1]
     # the same map as Rao-format triples (counts = wish^-3), on the device all the way
     i, j = numpy.nonzero(numpy.triu(wm, 1))
     res = 1000
     triples = numpy.stack([i * float(res), j * float(res), wm[i, j] ** -3.0], axis=1)
-    t = bb.StructureSolver(n_iter=40, dtype="float64", block_steps=True).fit_triples(triples, res, n - 1, init=x0)
+    t = bb.StructureSolver(n_iter=40, dtype="float64", degree_steps=True).fit_triples(triples, res, n - 1, init=x0)
     assert numpy.abs(t.stress_ / a.stress_ - 1).max() < 1e-9
+    # the same map as a DENSE matrix with holes (what a real ContactMap is): same degrees,
+    # same factors, same run up to the order of the partial sums -- in fp32 too
+    dn = bb.StructureSolver(n_iter=40, dtype="float64", kind="wish", degree_steps=True).fit(wm, init=x0)
+    assert numpy.abs(dn.stress_ / a.stress_ - 1).max() < 1e-10
+    d32 = bb.StructureSolver(n_iter=10, dtype="float32", kind="wish", degree_steps=True).fit(wm, init=x0)
+    assert numpy.abs(d32.stress_ / a.stress_[:10] - 1).max() < 1e-5
+    # a complete map: every bin has n - 1 partners, nothing changes (bit for bit)
     d0 = bb.StructureSolver(n_iter=3, dtype="float64", kind="wish").fit(w, init=x0)
-    d1 = bb.StructureSolver(n_iter=3, dtype="float64", kind="wish", block_steps=True).fit(w, init=x0)
-    assert numpy.array_equal(d0.structure_, d1.structure_)
+    d1 = bb.StructureSolver(n_iter=3, dtype="float64", kind="wish", degree_steps=True).fit(w, init=x0)
+    assert numpy.array_equal(d0.structure_, d1.structure_) and d1.lr_ == 1.0 / (2 * n)
 
 
 def test_round4_entry_points_reject_bad_arguments():

@@ -615,5 +615,10 @@ def test_genome_boundaries_and_block_tile_list():
     assert (cnt <= numpy.repeat(degs, vw)[:n]).all()
     lr, scale = block_step_factors(n, (ti, tj), "float32")
     assert lr == 1.0 / (2 * deg) and scale.min() == 1.0 and numpy.allclose(scale * degs, deg)
+    from blueberry_amd.solver import degree_step_factors
+    lr_d, sc_d = degree_step_factors(cnt)
+    assert lr_d == 1.0 / (2 * (cnt.max() + 1)) and sc_d.min() == 1.0
+    assert numpy.allclose(lr_d * sc_d, 1.0 / (2 * (cnt + 1.0)))
+    assert degree_step_factors(numpy.full(7, 6)) == (1.0 / 14, None)      # a complete map of 7 bins
     with pytest.raises(ValueError):
         tiles_from_blocks(n, [0, 10, 5, n], band, "float32")

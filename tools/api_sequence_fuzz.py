@@ -151,16 +151,22 @@ def one_sequence(rng, case):
                 continue
             if op == "block_steps":
                 lay = e.layout()
-                sc = None if rng.random() < 0.3 else rng.uniform(0.3, 1.7, lay["n_blocks"])
+                per_bin_form = rng.random() < 0.5                         # either entry point
+                sc = None if rng.random() < 0.3 else rng.uniform(
+                    0.3, 1.7, n if per_bin_form else lay["n_blocks"])
                 try:
-                    e.set_block_steps(sc)
+                    (e.set_bin_steps if per_bin_form else e.set_block_steps)(sc)
                     went = True
                 except RuntimeError:
                     went = False
                 if went == m.pending:                 # refused exactly while a gradient is pending
                     raise AssertionError("set_block_steps went through: %s, pending: %s" % (went, m.pending))
                 if went:
-                    m.per_bin = None if sc is None else numpy.repeat(sc, lay["vw"])[:n, None]
+                    m.per_bin = (None if sc is None else sc[:, None] if per_bin_form
+                                 else numpy.repeat(sc, lay["vw"])[:n, None])
+                    if m.w is not None and rng.random() < 0.3:           # the degree count, while here
+                        if not numpy.array_equal(e.degrees(), (m.w > 0).sum(axis=0)):
+                            raise AssertionError("degrees differ")
                     want = "units" if (sweep or sc is not None or n > 4096) else "row_owner"
                     if e.iteration_path()[0] != want:
                         raise AssertionError("iteration path %s, expected %s" % (e.iteration_path()[0], want))
