@@ -108,8 +108,8 @@ struct bb_solver {
     // iteration (row_owner_kernel); the units stay resident too and serve every other
     // entry point (grad / apply, stress, matvec)
     bool row_owner = false;
-    bool row_owner_built = false;        // created with the row-owner buffers (row_owner can be
-                                         // switched off later: several maps, block steps)
+    bool row_owner_built = false;        // created with the row-owner buffers (bb_solver_set_maps
+                                         // switches row_owner off)
     bool bin_steps = false;              // d_bin_scale set by bb_solver_set_bin_steps / _block_steps
     void *d_full = nullptr, *d_X2 = nullptr;
     int64_t full_ld = 0;
@@ -749,7 +749,7 @@ int launch_row_owner_t(bb_solver *s, double lr, bool fold_prev, bool update) {
     BB_HIP_CHECK(bb::launch(row_owner_kernel<T, WPRV>, dim3(grid), dim3(256), 0, s->stream,          \
                             (const T *)s->d_full, s->full_ld, (int)s->L.n_bins, (const T *)s->d_X,  \
                             (T *)s->d_X2, (T *)s->d_V, (T)lr, (T)s->momentum, prev, s->ro_blocks,   \
-                            hist_prev, out))
+                            hist_prev, out, (const T *)s->d_bin_scale))
     if (s->ro_wpr == 4) BB_ROW(4);
     else if (s->ro_wpr == 2) BB_ROW(2);
     else BB_ROW(1);
@@ -1043,10 +1043,6 @@ int bb_solver_set_bin_steps(bb_solver *s, const double *scale, int64_t n_bins) {
         hipFree(s->d_bin_scale);
         s->d_bin_scale = nullptr;
         s->bin_steps = false;
-        if (s->row_owner_built && !s->row_owner) {
-            s->row_owner = true;
-            if (s->have_wish) BB_TRY(refresh_full(s));
-        }
         return BB_OK;
     }
     BB_REQUIRE(n_bins == s->L.n_bins, "bb_solver_set_bin_steps: one factor per bin");
@@ -1057,8 +1053,7 @@ int bb_solver_set_bin_steps(bb_solver *s, const double *scale, int64_t n_bins) {
         padded[(size_t)i] = scale[i];
     }
     BB_TRY(upload_bin_scale(s, padded.data()));
-    s->bin_steps = true;
-    s->row_owner = false;          // the sweep: its reduce knows the factors
+    s->bin_steps = true;           // (the sweep's reduce and the row-owner kernel both know them)
     return BB_OK;
 }
 

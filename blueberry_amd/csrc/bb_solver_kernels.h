@@ -2097,7 +2097,8 @@ template <typename T, int WPR>
 __global__ __launch_bounds__(256) void row_owner_kernel(
     const T *__restrict__ full, int64_t ld, int n, const T *__restrict__ Xin,
     T *__restrict__ Xout, T *__restrict__ V, T lr, T mu, const double *__restrict__ part_prev,
-    int n_prev, double *__restrict__ hist_prev, double *__restrict__ part_out) {
+    int n_prev, double *__restrict__ hist_prev, double *__restrict__ part_out,
+    const T *__restrict__ bin_scale) {
     constexpr int ROWS = 4 / WPR;                 // rows per workgroup
     __shared__ double sh[256];
     __shared__ T red[4][4];
@@ -2175,11 +2176,16 @@ __global__ __launch_bounds__(256) void row_owner_kernel(
         }
     }
     if (i < n && part == 0 && lane == 63) {
-        // SPEC 2.3 / 2.4: g = 2 * sum; V <- mu V - lr g; X <- X + V
+        // SPEC 2.3 / 2.4: g = 2 * sum (2.4.1: times the bin's factor); V <- mu V - lr g; X <- X + V
         const int64_t o = 3 * (int64_t)i;
-        const T vx = mu * V[o] - lr * (T(2) * gx);
-        const T vy = mu * V[o + 1] - lr * (T(2) * gy);
-        const T vz = mu * V[o + 2] - lr * (T(2) * gz);
+        T g0 = T(2) * gx, g1 = T(2) * gy, g2 = T(2) * gz;
+        if (bin_scale) {
+            const T c = bin_scale[i];
+            g0 = c * g0; g1 = c * g1; g2 = c * g2;
+        }
+        const T vx = mu * V[o] - lr * g0;
+        const T vy = mu * V[o + 1] - lr * g1;
+        const T vz = mu * V[o + 2] - lr * g2;
         V[o] = vx; V[o + 1] = vy; V[o + 2] = vz;
         Xout[o] = xi + vx; Xout[o + 1] = yi + vy; Xout[o + 2] = zi + vz;
     }

@@ -169,8 +169,8 @@ BB_API int bb_solver_stress_maps(bb_solver *s, double *stress, int n_maps);
  *                              list alone gives, without a pass over the data
  * The gradient of bin i is scaled where it leaves the reduce -- into the update, the
  * exchange buffer (bb_solver_grad then holds scale * g) or the peers' arenas -- so it works
- * on any number of ranks with every exchange; every rank passes the same factors.  Maps of at
- * most 4,096 bins on one rank iterate with the unit sweep while factors are set.
+ * on any number of ranks with every exchange; every rank passes the same factors (maps of at
+ * most 4,096 bins on one rank keep their one launch per iteration: its kernel scales too).
  * BB_ERR_STATE for a solver of several maps (bb_solver_set_maps gives each map its step)
  * and while a bb_solver_grad is pending.  No counterpart in the reference (it has no solver;
  * SURVEY.md 0). */

@@ -1571,10 +1571,13 @@ def test_block_steps_vs_oracle(dtype, tol, mu):
     e.close()
 
 
-def test_block_steps_small_maps_and_errors():
-    """With factors set a map of at most 4,096 bins iterates with the unit sweep (its reduce
-    knows the blocks) and goes back to one launch per iteration when they are cleared --
-    with the full matrix rebuilt; bad arguments and call sequences are refused."""
+@pytest.mark.parametrize("sweep", [False, True])
+def test_block_steps_small_maps_and_errors(sweep, monkeypatch):
+    """A map of at most 4,096 bins keeps its one launch per iteration with factors set (the
+    row-owner kernel scales bin i's gradient itself), and the unit sweep gives the same;
+    bad arguments and call sequences are refused."""
+    monkeypatch.setenv("BB_ROW_OWNER_MAX", "0" if sweep else "4096")
+    path = "units" if sweep else "row_owner"
     n, k = 1300, 4
     lr = 1.0 / (2 * n)
     w = _oracle.wish_from_coords(_oracle.random_walk(n, seed=3))
@@ -1583,10 +1586,10 @@ def test_block_steps_small_maps_and_errors():
     nb = e.layout()["n_blocks"]
     vw = e.layout()["vw"]
     scale = numpy.linspace(0.5, 1.5, nb)
-    assert e.iteration_path()[0] == "row_owner"
+    assert e.iteration_path()[0] == path
     e.set_block_steps(scale)
-    assert e.iteration_path()[0] == "units"
-    e.set_wish_dense(w, "wish", 3.0)                   # (set while the full matrix is not in use)
+    assert e.iteration_path()[0] == path
+    e.set_wish_dense(w, "wish", 3.0)
     e.set_coords(x0)
     e.iterate(k, lr)
     X, V, hist = x0.copy(), numpy.zeros_like(x0), []
@@ -1613,7 +1616,7 @@ def test_block_steps_small_maps_and_errors():
     with pytest.raises(ValueError, match="one factor per bin"):
         e.set_bin_steps(numpy.ones(n + 1))
     e.set_block_steps(None)
-    assert e.iteration_path()[0] == "row_owner"
+    assert e.iteration_path()[0] == path
     e.set_coords(x0)
     e.iterate(k, lr)
     X_ref, h_ref = _oracle.load().solve(w, x0, k, lr)
@@ -1696,6 +1699,37 @@ def test_structure_solver_degree_steps():
     d0 = bb.StructureSolver(n_iter=3, dtype="float64", kind="wish").fit(w, init=x0)
     d1 = bb.StructureSolver(n_iter=3, dtype="float64", kind="wish", degree_steps=True).fit(w, init=x0)
     assert numpy.array_equal(d0.structure_, d1.structure_) and d1.lr_ == 1.0 / (2 * n)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_degree_steps_on_a_uniformly_sparse_small_map(dtype):
+    """A chromosome-sized DENSE matrix most of whose pairs have no contact (what a real map
+    is): every bin has about 8 % of the others as partners, so lr='auto' = 1 / (2 N) is twelve
+    times shorter than any bin needs.  degree_steps=True steps by 1 / (2 (deg_i + 1)): still a
+    descent, far lower stress after the same iterations -- on the one-launch-per-iteration
+    path (N <= 4,096), whose kernel applies the factors itself."""
+    n, k = 2000, 40
+    xs = _oracle.random_walk(n, seed=11)
+    w = _oracle.wish_from_coords(xs)
+    rng = numpy.random.default_rng(12)
+    keep = numpy.triu(rng.random((n, n)) < 0.08, 1)
+    keep |= numpy.triu(numpy.ones((n, n), dtype=bool), 1) & ~numpy.triu(numpy.ones((n, n), dtype=bool), 4)
+    wm = numpy.where(keep | keep.T, w, 0.0)
+    x0 = _oracle.noisy_init(xs, seed=13)
+    a = bb.StructureSolver(n_iter=k, dtype=dtype, kind="wish", degree_steps=True).fit(wm, init=x0)
+    b = bb.StructureSolver(n_iter=k, dtype=dtype, kind="wish").fit(wm, init=x0)
+    deg = (wm > 0).sum(axis=0)
+    assert a.lr_ == 1.0 / (2 * (deg.max() + 1)) and a.lr_ > 8 * b.lr_
+    assert (numpy.diff(a.stress_) <= 1e-6 * a.stress_[:-1]).all()
+    assert a.stress_[-1] < 0.05 * b.stress_[-1], (a.stress_[-1], b.stress_[-1])
+    X, hist = x0.copy(), []
+    scale = (deg.max() + 1.0) / (deg + 1.0)
+    for _ in range(5):
+        s_, g = _oracle.load().stress_grad(wm, X, f64=dtype == "float64")
+        X = X - a.lr_ * scale[:, None] * g
+        hist.append(s_)
+    tol = 1e-12 if dtype == "float64" else 1e-5
+    assert numpy.abs(a.stress_[:5] / numpy.array(hist) - 1).max() < tol
 
 
 def test_round4_entry_points_reject_bad_arguments():

@@ -167,7 +167,7 @@ def one_sequence(rng, case):
                     if m.w is not None and rng.random() < 0.3:           # the degree count, while here
                         if not numpy.array_equal(e.degrees(), (m.w > 0).sum(axis=0)):
                             raise AssertionError("degrees differ")
-                    want = "units" if (sweep or sc is not None or n > 4096) else "row_owner"
+                    want = "units" if (sweep or n > 4096) else "row_owner"
                     if e.iteration_path()[0] != want:
                         raise AssertionError("iteration path %s, expected %s" % (e.iteration_path()[0], want))
                     DONE[op] = DONE.get(op, 0) + 1
