@@ -1032,9 +1032,9 @@ int bb_solver_set_maps(bb_solver *s, int n_maps, const int64_t *bin_begin, const
 
 int bb_solver_set_bin_steps(bb_solver *s, const double *scale, int64_t n_bins) {
     BB_REQUIRE(s != nullptr, "bb_solver_set_bin_steps: solver is NULL");
-    if (s->n_maps > 1)
-        return bb::fail(BB_ERR_STATE, "bb_solver_set_bin_steps: a solver of several maps has its "
-                                      "steps from bb_solver_set_maps");
+    if (s->n_maps > 1 && scale == nullptr)
+        return bb::fail(BB_ERR_STATE, "bb_solver_set_bin_steps: a solver of several maps always has "
+                                      "factors (bb_solver_set_maps sets each map's; pass new ones)");
     if (s->grad_pending)
         return bb::fail(BB_ERR_STATE, "bb_solver_set_bin_steps: a bb_solver_grad is pending");
     BB_TRY(bb::enter_device(s->device));

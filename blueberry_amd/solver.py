@@ -1092,6 +1092,17 @@ class StructureSolver(object):
                 else:
                     m = src.to_host() if getattr(src, "is_resident", False) else src
                     eng.set_wish_dense_block(m, o, self.kind, self.alpha)
+            if self.degree_steps:
+                # SPEC 2.4.1 per map: bin i steps by 1 / (2 (deg_i + 1)) (lr = 1 below); a float
+                # `lr` stays the step of each map's best-connected bin
+                deg = eng.degrees()
+                steps = numpy.ones(total)
+                for q, (o, n) in enumerate(zip(off, sizes)):
+                    d = deg[o:o + n]
+                    top = 1.0 / (2.0 * (d.max() + 1.0)) if self.lr == "auto" else float(self.lr)
+                    steps[o:o + n] = top * (d.max() + 1.0) / (d + 1.0)
+                    lrs[q] = top
+                eng.set_bin_steps(steps)
             eng.set_coords(x0)
             if self.momentum:
                 eng.set_momentum(self.momentum)

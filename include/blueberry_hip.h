@@ -171,8 +171,10 @@ BB_API int bb_solver_stress_maps(bb_solver *s, double *stress, int n_maps);
  * exchange buffer (bb_solver_grad then holds scale * g) or the peers' arenas -- so it works
  * on any number of ranks with every exchange; every rank passes the same factors (maps of at
  * most 4,096 bins on one rank keep their one launch per iteration: its kernel scales too).
- * BB_ERR_STATE for a solver of several maps (bb_solver_set_maps gives each map its step)
- * and while a bb_solver_grad is pending.  No counterpart in the reference (it has no solver;
+ * On a solver of several maps the factors REPLACE the per-map steps of bb_solver_set_maps
+ * (pass lr = 1 to bb_solver_iterate and scale[i] = the step of bin i, e.g.
+ * 1 / (2 (degree[i] + 1)); clearing them there is BB_ERR_STATE).  BB_ERR_STATE while a
+ * bb_solver_grad is pending.  No counterpart in the reference (it has no solver;
  * SURVEY.md 0). */
 BB_API int bb_solver_degrees(bb_solver *s, int64_t *degree, int64_t n_bins);
 BB_API int bb_solver_set_bin_steps(bb_solver *s, const double *scale, int64_t n_bins);

@@ -63,6 +63,12 @@ class OracleEngine(object):
         return numpy.triu(own, 1)
 
     def degrees(self):
+        if getattr(self, "maps", None):
+            deg = numpy.zeros(self.n_bins, dtype=numpy.int64)
+            for a, w, _ in self.maps:
+                if w is not None:
+                    deg[a:a + w.shape[0]] = (numpy.triu(w, 1) > 0).sum(axis=0) + (numpy.triu(w, 1) > 0).sum(axis=1)
+            return deg
         on = self._own_pairs() & (self.w > 0)
         return (on.sum(axis=0) + on.sum(axis=1)).astype(numpy.int64)
 
@@ -136,6 +142,8 @@ class OracleEngine(object):
             for a, w, scale in self.maps:
                 n = w.shape[0]
                 s, g = self.oracle.stress_grad(w, self.X[a:a + n], f64=self.dtype == "float64")
+                if getattr(self, "bin_scale", None) is not None:      # these replace the maps' steps
+                    g, scale = g * self.bin_scale[a:a + n, None], 1.0
                 self.V[a:a + n] = self.mu * self.V[a:a + n] - lr * scale * g
                 self.X[a:a + n] += self.V[a:a + n]
                 row.append(s)

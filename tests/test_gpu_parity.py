@@ -1438,6 +1438,20 @@ def test_fit_many_defaults_early_stop_and_spectral():
         bb.StructureSolver().fit_many([])
     with pytest.raises(ValueError):
         bb.StructureSolver().fit_many([numpy.zeros((3, 4))])
+    # degree_steps: every map's bins step by their own degrees -- map by map the single fit()
+    holes = []
+    for q, m in enumerate(mats):
+        keep = numpy.triu(numpy.random.default_rng(50 + q).random(m.shape) < 0.15, 1)
+        keep |= numpy.triu(numpy.ones(m.shape, dtype=bool), 1) & ~numpy.triu(numpy.ones(m.shape, dtype=bool), 3)
+        holes.append(numpy.where(keep | keep.T, m, 0.0))
+    d = bb.StructureSolver(n_iter=8, dtype="float64", kind="wish", degree_steps=True).fit_many(holes, inits=near)
+    u = bb.StructureSolver(n_iter=8, dtype="float64", kind="wish").fit_many(holes, inits=near)
+    for q, m in enumerate(holes):
+        one = bb.StructureSolver(n_iter=8, dtype="float64", kind="wish", degree_steps=True).fit(m, init=near[q])
+        assert d.lrs_[q] == one.lr_
+        assert numpy.abs(d.stresses_[q] / one.stress_ - 1).max() < 1e-11
+        assert _rel(d.structures_[q], one.structure_) < 1e-11
+        assert d.stresses_[q][-1] < 0.5 * u.stresses_[q][-1]
 
 
 def test_several_maps_engine_level_properties():
@@ -1635,8 +1649,9 @@ def test_block_steps_small_maps_and_errors(sweep, monkeypatch):
     e = HipEngine(1024, "float32", tiles=(numpy.array([0, 1], dtype=numpy.int32),
                                           numpy.array([0, 1], dtype=numpy.int32)))
     e.set_maps([0, 512, 1024], [1.0, 1.0])
+    e.set_block_steps(numpy.ones(2))                   # replaces the maps' factors ...
     with pytest.raises(RuntimeError, match="several maps"):
-        e.set_block_steps(numpy.ones(2))
+        e.set_block_steps(None)                        # ... which cannot be cleared
     e.close()
 
 

@@ -271,6 +271,20 @@ def test_fit_many_host_logic_with_the_oracle_engine(oracle, dtype):
         one = bb.StructureSolver(n_iter=2, dtype=dtype, kind="wish", seed=5, engine=OracleEngine,
                                  distributed=False).fit(mats[q])
         assert numpy.array_equal(a.structures_[q], one.structure_)
+    # degree_steps: per-bin factors replace the per-map steps; map by map the single fit()
+    holes = []
+    for q, m in enumerate(mats[:3]):
+        keep = numpy.triu(numpy.random.default_rng(q).random(m.shape) < 0.3, 1)
+        keep |= numpy.triu(numpy.ones(m.shape, dtype=bool), 1) & ~numpy.triu(numpy.ones(m.shape, dtype=bool), 2)
+        holes.append(numpy.where(keep | keep.T, m, 0.0))
+    d = bb.StructureSolver(n_iter=3, dtype=dtype, kind="wish", engine=OracleEngine, distributed=False,
+                           degree_steps=True).fit_many(holes, inits=x0[:3])
+    for q, m in enumerate(holes):
+        one = bb.StructureSolver(n_iter=3, dtype=dtype, kind="wish", engine=OracleEngine,
+                                 distributed=False, degree_steps=True).fit(m, init=x0[q])
+        assert d.lrs_[q] == one.lr_ == 1.0 / (2 * ((m > 0).sum(axis=0).max() + 1))
+        assert numpy.abs(d.stresses_[q] / one.stress_ - 1).max() < 1e-12
+        assert numpy.abs(d.structures_[q] - one.structure_).max() < 1e-12 * numpy.abs(one.structure_).max()
     with pytest.raises(ValueError):
         bb.StructureSolver(engine=OracleEngine, distributed=False).fit_many(mats, inits=x0[:2])
     with pytest.raises(ValueError):
