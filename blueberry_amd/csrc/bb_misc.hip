@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kScanBlock) void bh_apply_kernel(double *__restrict
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
         const int64_t i = base + k;
-        if (i < d && threadIdx.x * kItems + k < first) q[i] = ref_max(pre, q[i]);
+        if (i < d && (int)threadIdx.x * kItems + k < first) q[i] = ref_max(pre, q[i]);
     }
 }
 
