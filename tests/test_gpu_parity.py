@@ -1312,7 +1312,8 @@ def test_genome10kb_workload_full_size_vs_oracle_and_properties(oracle):
     (i) K = 3 iterations against the oracle's tile-list loop on the same pair set (fp32
     1e-5: stress history and coordinates); (ii) size-independent properties: zero stress
     and a fixed point at the generating coordinates, monotone decrease from the noisy
-    start, bitwise reproducibility, 3 rank shares that sum to the 1-rank gradient."""
+    start, bitwise reproducibility, 3 rank shares that sum to the 1-rank gradient; (iii) the
+    degree count and a step per bin (SPEC 2.4.1) against the oracle at the same size."""
     from blueberry_amd.solver import max_degree, tiles_from_blocks
     from blueberry_amd.utils import genome_boundaries
     n, k = 309568, 3
@@ -1339,6 +1340,29 @@ def test_genome10kb_workload_full_size_vs_oracle_and_properties(oracle):
     e.set_coords(x0)
     e.iterate(k, lr)
     assert numpy.array_equal(X, e.get_coords()) and numpy.array_equal(h, e.stress_history())
+    # (iii) SPEC 2.4.1 at full size: the degrees counted on the device are the tile list's
+    # (every stored pair of this map is a constraint), and K iterations with a step per bin
+    # equal the oracle's loop with the same factors
+    from blueberry_amd.solver import degree_step_factors
+    deg = e.degrees()
+    nb, vw = e.layout()["n_blocks"], 512
+    have = numpy.zeros((nb, nb), dtype=bool)
+    have[tiles[0], tiles[1]] = True
+    have |= have.T
+    width = numpy.minimum(vw, n - numpy.arange(nb) * vw)
+    assert numpy.array_equal(deg, numpy.repeat(have @ width, vw)[:n] - 1)
+    assert int(deg.sum()) == 2 * pairs
+    lr_d, scale = degree_step_factors(deg)
+    X_ref, h_ref = _oracle.solve_gen_mt(xs, x0, k, lr_d, _host_threads(), tiles=tiles, f64=False,
+                                        bin_scale=scale)
+    e.set_bin_steps(scale)
+    e.set_coords(x0)
+    e.iterate(k, lr_d)
+    err_s, err_x = float(numpy.abs(e.stress_history() / h_ref - 1).max()), _rel(e.get_coords(), X_ref)
+    print("genome10kb with a step per bin: stress %.2e coords %.2e; after %d steps %.3f of the start's "
+          "stress (one step for all: %.3f)" % (err_s, err_x, k, h_ref[-1] / h_ref[0], h[-1] / h[0]))
+    assert err_s < 1e-5 and err_x < 1e-5 and h_ref[-1] / h_ref[0] < h[-1] / h[0]
+    e.set_bin_steps(None)
     e.set_coords(x0)
     e.grad()
     full = e.read_exchange()
