@@ -1571,6 +1571,15 @@ def test_block_steps_vs_oracle(dtype, tol, mu):
                                         f64=dtype == "float64", blk_scale=scale)
     e = HipEngine(n, dtype, tiles=tiles)
     e.set_wish_from_coords(xs)
+    if mu == 0.0:
+        # the degree count on this layout (fp64 here is the wide 2 x 512 unit): every stored
+        # pair of the map is a constraint, so the degrees are the tile list's
+        nb = e.layout()["n_blocks"]
+        have = numpy.zeros((nb, nb), dtype=bool)
+        have[tiles[0], tiles[1]] = True
+        have |= have.T
+        width = numpy.minimum(vw, n - numpy.arange(nb) * vw)
+        assert numpy.array_equal(e.degrees(), numpy.repeat(have @ width, vw)[:n] - 1)
     e.set_block_steps(scale)
     e.set_momentum(mu)
     e.set_coords(x0)
