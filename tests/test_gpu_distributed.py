@@ -657,6 +657,74 @@ def test_multi_rank_spectral_start_stays_on_the_device(dtype, tol, world, form, 
         assert numpy.abs(Xm[0] - X1m).max() < 1e3 * tol * numpy.abs(X1m).max()
 
 
+def _degree_map(n):
+    """Two dense blocks (5 : 1) joined by a band: the bins' degrees differ by a factor of 5."""
+    from tests import _oracle
+    xs = _oracle.random_walk(n)
+    w = _oracle.wish_from_coords(xs)
+    i, j = numpy.indices((n, n))
+    cut = (5 * n) // 6
+    keep = ((i < cut) & (j < cut)) | ((i >= cut) & (j >= cut)) | (numpy.abs(i - j) <= 40)
+    return numpy.where(keep, w, 0.0), _oracle.noisy_init(xs)
+
+
+def _worker_degree_fit(rank, world, port, n, dtype, comm, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["BB_COMM"] = comm
+        os.environ["BB_PEER_TIMEOUT_MS"] = "20000"
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import blueberry_amd as bb
+        w, x0 = _degree_map(n)
+        s = bb.StructureSolver(n_iter=6, dtype=dtype, kind="wish", device=0, degree_steps=True,
+                               momentum=0.3).fit(w, init=x0)
+        q.put((rank, s.structure_, s.stress_, s.exchange_, s.lr_))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, traceback.format_exc(), None, None, None))
+
+
+@pytest.mark.parametrize("dtype,tol,world,comm", [("float64", 1e-11, 2, "peer"),
+                                                   ("float32", 1e-5, 3, "peer"),
+                                                   ("float64", 1e-11, 2, "host")])
+def test_fit_with_degree_steps_across_processes(dtype, tol, world, comm):
+    """fit(degree_steps=True) on real processes sharing the test GPU: every rank counts the
+    degrees of its own units on the device, the counts are summed over the ranks, the same
+    per-bin factors go to every rank's solver, and the scaled gradients travel through the
+    peer exchange (arenas over HIP IPC) or the host-staged sum.  Equal to one process."""
+    import torch.multiprocessing as mp
+    import blueberry_amd as bb
+    n = 2300
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_degree_fit, args=(r, world, port, n, dtype, comm, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert not isinstance(r[1], str), r[1]
+        assert r[3] == comm
+    w, x0 = _degree_map(n)
+    one = bb.StructureSolver(n_iter=6, dtype=dtype, kind="wish", degree_steps=True, momentum=0.3,
+                             distributed=False).fit(w, init=x0)
+    deg = (w > 0).sum(axis=0)
+    assert one.lr_ == 1.0 / (2 * (deg.max() + 1)) and deg.max() > 4 * deg.min()
+    for rank, X, h, _, lr in results:
+        assert lr == one.lr_
+        assert numpy.abs(h / one.stress_ - 1).max() < tol
+        assert numpy.abs(X - one.structure_).max() < tol * numpy.abs(one.structure_).max()
+    for r in results[1:]:
+        assert numpy.array_equal(r[1], results[0][1])
+
+
 def _worker_spectral_fit(rank, world, port, n, dtype, comm, q):
     try:
         sys.path.insert(0, ROOT)
