@@ -87,6 +87,19 @@ def close(a, b, tol, scale=None):
     return bool(numpy.abs(a - b).max() <= tol * s)
 
 
+def close_stress(a, b, tol, model):
+    """Stress values: relative, above a floor of rounding noise -- at a spectral start of an
+    exact map the stress IS rounding noise (1e-13 of sum delta^2 in fp64), and two correct
+    computations of it agree in order of magnitude only."""
+    a, b = numpy.asarray(a, dtype=float), numpy.asarray(b, dtype=float)
+    if a.shape != b.shape:
+        return False
+    if a.size == 0:
+        return True
+    floor = (1e-10 if model.f64 else 1e-7) * float((model.w * model.w).sum())
+    return bool((numpy.abs(a - b) <= tol * numpy.abs(b) + floor).all())
+
+
 DONE = {}                                            # calls that went through, per kind
 
 
@@ -209,7 +222,7 @@ def one_sequence(rng, case):
                 both(lambda: e.apply(lr), lambda: m.apply(lr))
             elif op == "stress":
                 r_e, r_m = both(e.stress, m.stress)
-                if exp_err is None and not close(r_e, r_m, tol):
+                if exp_err is None and not close_stress(r_e, r_m, tol, m):
                     raise AssertionError("stress %r vs %r" % (r_e, r_m))
             elif op == "matvec":
                 x = rng.standard_normal((n, 3))
@@ -217,7 +230,7 @@ def one_sequence(rng, case):
                 if exp_err is None and not close(r_e, r_m, tol):
                     raise AssertionError("matvec differs by %g" % numpy.abs(r_e - r_m).max())
             elif op == "spectral":
-                if m.w is None or m.pending or n < 4 or not (numpy.triu(m.w, 1) > 0).all():
+                if m.w is None or m.pending or n < 4 or not (m.w[numpy.triu_indices(n, 1)] > 0).all():
                     continue                         # (complete maps only: the start is then exact)
                 e.spectral_init_device(40, rng.standard_normal((n, 3)), tol=1e-3)
                 x = e.get_coords()
@@ -239,7 +252,7 @@ def one_sequence(rng, case):
                 if not close(x, m.X, tol * 50, scale):
                     raise AssertionError("coordinates differ by %g (scale %g)"
                                          % (numpy.abs(x - m.X).max(), scale))
-                if not close(h, numpy.array(m.hist), tol * 50):
+                if not close_stress(h, numpy.array(m.hist), tol * 50, m):
                     raise AssertionError("history %r vs %r" % (h, m.hist))
         return True, log
     except AssertionError as exc:
