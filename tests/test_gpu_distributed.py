@@ -412,13 +412,17 @@ from tests import _oracle
 n, k = 900, 6
 xs = _oracle.random_walk(n); w = _oracle.wish_from_coords(xs); x0 = _oracle.noisy_init(xs)
 lr = 1.0 / (2 * n)
-out = {}
-# world=2 forces grad/all-reduce/apply; BB_COMM picks the collective's owner
-for name, world, comm in (("fused", 1, None), ("exchange", 2, "rccl"), ("torch", 2, "torch"),
-                          ("peer", 2, "peer"), ("auto", 2, "auto")):
+# the second pass: the same with a step per bin (bb_solver_set_bin_steps: the gradient is
+# scaled where it leaves the reduce, so every transport carries it)
+for factors in (None, numpy.random.default_rng(3).uniform(0.5, 1.5, n)):
+  out = {}
+  # world=2 forces grad/all-reduce/apply; BB_COMM picks the collective's owner
+  for name, world, comm in (("fused", 1, None), ("exchange", 2, "rccl"), ("torch", 2, "torch"),
+                            ("peer", 2, "peer"), ("auto", 2, "auto")):
     if comm: os.environ["BB_COMM"] = comm
     e = HipEngine(n, "float32")
     e.set_wish_dense(w, "wish", 3.0); e.set_coords(x0)
+    if factors is not None: e.set_bin_steps(factors)
     if comm == "auto":
         # the trial: both transports from the same start, coordinates compared, the
         # faster one kept, the start restored
@@ -434,13 +438,15 @@ for name, world, comm in (("fused", 1, None), ("exchange", 2, "rccl"), ("torch",
             assert e.comm_world() == 1                  # what RCCL itself reports
             e.sync_timeout(10000)
     out[name] = (e.get_coords(), e.stress_history()); e.close()
-assert numpy.array_equal(out["torch"][0], out["exchange"][0])      # same kernels, same sums
-assert numpy.array_equal(out["peer"][0], out["exchange"][0])       # one rank: nothing to reorder
-assert numpy.array_equal(out["auto"][0], out["exchange"][0])
-assert numpy.array_equal(out["peer"][1], out["exchange"][1])
-assert len(_lib.hip_runtimes_loaded()) == 1, _lib.hip_runtimes_loaded()
-assert numpy.abs(out["fused"][0] - out["exchange"][0]).max() < 1e-5 * numpy.abs(out["fused"][0]).max()
-assert numpy.abs(out["fused"][1] / out["exchange"][1] - 1).max() < 1e-5
+  assert numpy.array_equal(out["torch"][0], out["exchange"][0])      # same kernels, same sums
+  assert numpy.array_equal(out["peer"][0], out["exchange"][0])       # one rank: nothing to reorder
+  assert numpy.array_equal(out["auto"][0], out["exchange"][0])
+  assert numpy.array_equal(out["peer"][1], out["exchange"][1])
+  assert len(_lib.hip_runtimes_loaded()) == 1, _lib.hip_runtimes_loaded()
+  assert numpy.abs(out["fused"][0] - out["exchange"][0]).max() < 1e-5 * numpy.abs(out["fused"][0]).max()
+  assert numpy.abs(out["fused"][1] / out["exchange"][1] - 1).max() < 1e-5
+  if factors is None: plain = out["fused"][0]
+assert numpy.abs(out["fused"][0] - plain).max() > 1e-3 * numpy.abs(plain).max()   # the factors did act
 dist.destroy_process_group()
 print("NCCL_PATH_OK")
 """
