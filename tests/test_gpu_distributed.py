@@ -460,6 +460,22 @@ def test_rccl_single_rank_device_path():
     assert "NCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_eight_ranks_over_the_peer_exchange_in_one_process():
+    """World size 8 -- what the scaling run uses -- rehearsed on one GPU: eight ranks of ONE
+    process (more than the six processes a box allows on its GPU), arenas connected directly,
+    random call sequences of tools/peer_sequence_fuzz.py (iterate_peer, the spectral start,
+    per-bin steps, the two-call path) against the one-rank model; ranks bit-identical after
+    every call.  Needs more hardware queues than the HIP runtime's default of four (streams
+    that share a queue deadlock when one waits for the other), hence a process of its own
+    with GPU_MAX_HW_QUEUES set; the one-launch form keeps to a size whose waiting workgroups
+    of all eight ranks fit one chip (the tool says why)."""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="32", BB_FUZZ_WORLDS="8,5", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "peer_sequence_fuzz.py"), "12", "7"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "FAILURES: 0" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "world=8" in r.stdout or "world=5" in r.stdout
+
+
 def test_peer_exchange_call_sequence_errors():
     """The peer entry points refuse to be used out of order or with handles that do
     not belong to this job (status codes + bb_last_error, no crash)."""

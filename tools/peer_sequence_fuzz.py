@@ -6,7 +6,7 @@ through the same exchange and sequence numbers), coordinates reset, momentum swi
 steps set and cleared, the two-call path (grad, host sum, apply) in between -- against the
 one-rank numpy / oracle model of tools/api_sequence_fuzz.py.  After every call all ranks must
 hold the SAME bits and agree with the model; a time-out (peer_status != 0) is a finding.
-Both forms of the exchange, 2 and 3 ranks, both dtypes.  Test infrastructure: uses the oracle.
+Both forms of the exchange, 2, 3 and 8 ranks, both dtypes.  Test infrastructure: uses the oracle.
 
     python tools/peer_sequence_fuzz.py [n_sequences] [seed]"""
 import ctypes
@@ -37,10 +37,21 @@ def connect(engs):
 
 
 def one_sequence(rng):
-    world = int(rng.choice([2, 3]))
+    # (BB_FUZZ_WORLDS=8: more ranks than the HIP runtime has hardware queues by default --
+    # GPU_MAX_HW_QUEUES=4 -- deadlock when they are streams of ONE process: a kernel that
+    # waits for a peer sits in front of that peer's kernel in the same queue.  Run such a
+    # rehearsal with GPU_MAX_HW_QUEUES=16 in the environment.)
+    world = int(rng.choice([int(v) for v in os.environ.get("BB_FUZZ_WORLDS", "2,3").split(",")]))
     n = int(rng.choice([700, 1100, 2600]))           # 2,600: above the row-owner switch for the model's twin too
     dtype = str(rng.choice(["float64", "float32"]))
     fused = bool(rng.integers(2))
+    if fused and world >= 8:
+        # ranks that share ONE GPU: the one-launch form's workgroups wait inside the kernel
+        # for their peers, and 8 ranks x 72 workgroups x 16 waves (n = 2,600) are more waves
+        # than the chip holds -- the ranks that are not resident can never deliver.  (On 8
+        # GPUs each holds its own 72.)  The rehearsal keeps to a size whose waiting
+        # workgroups all fit.
+        n = 700
     os.environ["BB_PEER_FUSED"] = "1" if fused else "0"
     os.environ["BB_PEER_TIMEOUT_MS"] = "20000"
     tol = 1e-10 if dtype == "float64" else 2e-4
