@@ -313,6 +313,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         n_dev = torch.cuda.device_count()      # counting does not initialise the GPU
+        if world > 5 * max(1, n_dev):
+            # a rehearsal with ranks sharing GPUs: the boxes of this pool allow six processes
+            # per GPU and the launcher is one of them -- stop before any rank opens the device
+            raise SystemExit("bench.py: %d ranks on %d GPU(s): at most 5 ranks may share a GPU "
+                             "here (tools/peer_sequence_fuzz.py rehearses 8 ranks in ONE process)"
+                             % (world, n_dev))
         if a.backend == "nccl" and world > max(1, n_dev):
             # more ranks than GPUs (a rehearsal on a smaller box): RCCL refuses two ranks
             # on one device, so the sum over ranks goes through gloo and host memory
