@@ -99,6 +99,7 @@ struct bb_solver {
     bool peer_fused = true;                 // reduce_exchange_kernel (BB_PEER_FUSED=0: two launches)
     PeerState *d_peer_state = nullptr;      // sticky failure flag + last complete exchange
     int peer_clock_khz = 100000;            // constant-rate clock behind wall_clock64()
+    int peer_ranks_on_gpu = 1;              // most ranks of the job on one GPU (a rehearsal: > 1)
     unsigned *d_peer_counter = nullptr;
     unsigned long long peer_seq = 0;        // iterations exchanged so far
     long long peer_limit_ticks = 0;
@@ -1742,7 +1743,12 @@ namespace {
 // rank's flag of exchange `peer_seq`, X <- X + (mu V - lr * sum over the ranks in rank order).
 int launch_peer_receive(bb_solver *s, void *X, double lr, double mu, double *stress_out) {
     const int64_t n3 = s->L.n_pad * 3, es = bb::elem_size(s->dtype);
-    const unsigned grid = (unsigned)std::min<int64_t>((n3 + 255) / 256, kPeerReceiveWGs);
+    // Ranks that share a GPU (a rehearsal) share its wave slots too: the receive kernels of ALL
+    // of them wait at once, and eight times 256 workgroups of 4 waves are every slot the chip
+    // has -- nobody's sweep could start (found by tools/world8_rehearsal.py).  The cap is
+    // divided among them; a thread then takes more elements.
+    const int64_t cap = std::max<int64_t>(8, (int64_t)kPeerReceiveWGs / (s->peer_ranks_on_gpu > 2 ? s->peer_ranks_on_gpu / 2 : 1));
+    const unsigned grid = (unsigned)std::min<int64_t>((n3 + 255) / 256, cap);
     const char *arena = (const char *)s->peer_arena +
                         (int64_t)(s->peer_seq & 1) * s->world * s->peer_slot_elems * es;
     const unsigned long long *flags =
@@ -1933,6 +1939,7 @@ int bb_solver_peer_connect(bb_solver *s, const void *handles) {
         // on every rank; small problems on a shared GPU do run in one launch).
         const char *env = getenv("BB_PEER_FUSED");
         s->peer_fused = env ? atoi(env) != 0 : most_on_one_gpu == 1;
+        s->peer_ranks_on_gpu = most_on_one_gpu;
         if (s->red_slices <= 0) s->peer_fused = false;
     }
     s->peer_connected = true;

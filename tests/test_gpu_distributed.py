@@ -476,6 +476,18 @@ def test_eight_ranks_over_the_peer_exchange_in_one_process():
     assert "world=8" in r.stdout or "world=5" in r.stdout
 
 
+def test_world_size_eight_at_full_sizes_on_one_gpu():
+    """The scaling run's world size at BASELINE's sizes: eight ranks of one process, each with
+    its 1/8 share of the units of the headline map (N = 50,000 dense fp32) and of config 5
+    (N = 309,568 block-sparse), iterate over the peer exchange and end where ONE rank ends
+    (1e-5; measured 6e-8), bit-identical among themselves (tools/world8_rehearsal.py; a
+    process of its own for the hardware queues)."""
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="32", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "world8_rehearsal.py")],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "world-8 rehearsal ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_peer_exchange_call_sequence_errors():
     """The peer entry points refuse to be used out of order or with handles that do
     not belong to this job (status codes + bb_last_error, no crash)."""
