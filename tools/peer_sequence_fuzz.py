@@ -45,12 +45,15 @@ def one_sequence(rng):
     n = int(rng.choice([700, 1100, 2600]))           # 2,600: above the row-owner switch for the model's twin too
     dtype = str(rng.choice(["float64", "float32"]))
     fused = bool(rng.integers(2))
-    if fused and world >= 8:
+    if fused and world > 3:
         # ranks that share ONE GPU: the one-launch form's workgroups wait inside the kernel
-        # for their peers, and 8 ranks x 72 workgroups x 16 waves (n = 2,600) are more waves
-        # than the chip holds -- the ranks that are not resident can never deliver.  (On 8
-        # GPUs each holds its own 72.)  The rehearsal keeps to a size whose waiting
-        # workgroups all fit.
+        # for their peers.  8 ranks x 72 workgroups x 16 waves (n = 2,600) are more waves than
+        # the chip holds -- the ranks that are not resident can never deliver -- and already
+        # 4-6 ranks' waiting workgroups (16 waves and 16 KB of LDS each) can keep a peer's
+        # sweep (150 KB of LDS per workgroup) off every CU: what bb_solver_peer_connect
+        # avoids by itself by choosing the two-launch form when ranks share a GPU.  (On 8 GPUs
+        # each holds its own 72.)  Forced here, the one-launch form keeps to a size whose
+        # waiting workgroups are few.
         n = 700
     os.environ["BB_PEER_FUSED"] = "1" if fused else "0"
     os.environ["BB_PEER_TIMEOUT_MS"] = "20000"
@@ -153,7 +156,7 @@ def one_sequence(rng):
                 raise AssertionError("history differs from the model after %s" % op)
             DONE[op] = DONE.get(op, 0) + 1
         return True, log
-    except AssertionError as exc:
+    except (AssertionError, RuntimeError) as exc:
         return False, log + ["FAIL: %s" % exc]
     finally:
         for e in engs:
