@@ -1481,7 +1481,12 @@ __global__ __launch_bounds__(128 * S) void reduce_sliced_kernel(ReduceParams<T> 
         // acknowledged (__syncthreads() waits vmcnt(0)): a release is a write-back of the
         // XCD's L2, and with all 16 waves of the workgroup issuing one the push cost 33 us
         // instead of 12 (tools/exchange_timing.py; reduce_kernel's workgroups have 2 waves).
+        // The wait is spelled out in EVERY storing wave: that __syncthreads() emits one is a
+        // code-generation detail (the memory model lets a workgroup-scope release omit it), and
+        // a flag that overtakes the data would make a peer sum stale partials silently.  It
+        // costs nothing: no cache write-back, and the barrier waits for the slowest wave anyway.
         __shared__ int last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope
