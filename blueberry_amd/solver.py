@@ -1014,7 +1014,10 @@ class StructureSolver(object):
                                         alpha=self.alpha, kind=self.kind, seed=self.seed,
                                         device=self._pick_device(world), distributed=False,
                                         engine=self._engine_factory, momentum=self.momentum,
-                                        init=self.init, tol=self.tol, check_every=self.check_every)
+                                        init=self.init, tol=self.tol, check_every=self.check_every,
+                                        spectral_iter=self.spectral_iter,
+                                        spectral_tol=self.spectral_tol,
+                                        degree_steps=self.degree_steps)
                 local._fit_many_local([maps[m] for m in mine[rank]], [inits[m] for m in mine[rank]])
                 part = (mine[rank], local.structures_, local.stresses_, local.lrs_)
             parts = [None] * world

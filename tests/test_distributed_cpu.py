@@ -258,11 +258,19 @@ def _many_worker(rank, world, port, q):
         mats = [_oracle.wish_from_coords(_oracle.random_walk(n, seed=q_)) for q_, n in enumerate(sizes)]
         s = bb.StructureSolver(n_iter=3, dtype="float64", kind="wish", seed=2,
                                engine=OracleEngine).fit_many(mats)      # picks up the gloo job
-        q.put((rank, s.structures_, s.stresses_, s.ranks_of_maps_))
+        # the options travel to the per-rank solvers: a step per bin from each map's degrees
+        holes = []
+        for q_, m in enumerate(mats[:3]):
+            keep = numpy.triu(numpy.random.default_rng(q_).random(m.shape) < 0.3, 1)
+            keep |= numpy.triu(numpy.ones(m.shape, dtype=bool), 1) & ~numpy.triu(numpy.ones(m.shape, dtype=bool), 2)
+            holes.append(numpy.where(keep | keep.T, m, 0.0))
+        d = bb.StructureSolver(n_iter=3, dtype="float64", kind="wish", seed=2, engine=OracleEngine,
+                               degree_steps=True).fit_many(holes)
+        q.put((rank, s.structures_, s.stresses_, s.ranks_of_maps_, d.lrs_, d.stresses_))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
-        q.put((rank, traceback.format_exc(), None, None))
+        q.put((rank, traceback.format_exc(), None, None, None, None))
 
 
 def test_fit_many_deals_the_maps_to_the_ranks(oracle):
@@ -291,6 +299,19 @@ def test_fit_many_deals_the_maps_to_the_ranks(oracle):
         X, h = oracle.solve(w, x0, 3, 1.0 / (2 * n))
         for r in results:
             assert numpy.array_equal(r[1][m], X) and numpy.array_equal(r[2][m], h)
+    # degree_steps reached the ranks' own solvers: every map's step is its best-connected bin's
+    import blueberry_amd as bb
+    from tests._engines import OracleEngine
+    for m in range(3):
+        w = _oracle.wish_from_coords(_oracle.random_walk(sizes[m], seed=m))
+        keep = numpy.triu(numpy.random.default_rng(m).random(w.shape) < 0.3, 1)
+        keep |= numpy.triu(numpy.ones(w.shape, dtype=bool), 1) & ~numpy.triu(numpy.ones(w.shape, dtype=bool), 2)
+        hm = numpy.where(keep | keep.T, w, 0.0)
+        one = bb.StructureSolver(n_iter=3, dtype="float64", kind="wish", seed=2, engine=OracleEngine,
+                                 distributed=False, degree_steps=True).fit(hm)
+        for r in results:
+            assert r[4][m] == one.lr_ == 1.0 / (2 * ((hm > 0).sum(axis=0).max() + 1))
+            assert numpy.abs(r[5][m] / one.stress_ - 1).max() < 1e-12
 
 
 # ---- select_exchange: the decision logic, with a scripted engine -----------------
