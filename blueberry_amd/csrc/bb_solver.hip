@@ -1073,16 +1073,16 @@ int bb_solver_degrees(bb_solver *s, int64_t *degree, int64_t n_bins) {
     BB_REQUIRE(n_bins == s->L.n_bins, "bb_solver_degrees: one count per bin");
     if (!s->have_wish) return bb::fail(BB_ERR_STATE, "bb_solver_degrees: no wish distances set");
     BB_TRY(bb::enter_device(s->device));
-    bb::DevBuf buf;
-    if (buf.alloc((size_t)s->L.n_pad * sizeof(int)) != hipSuccess)
-        return bb::fail(BB_ERR_NOMEM, "bb_solver_degrees: out of device memory");
-    BB_HIP_CHECK(hipMemsetAsync(buf.p, 0, (size_t)s->L.n_pad * sizeof(int), s->stream));
+    // (the staging buffer of set_coords / get_coords serves: 3 n_pad doubles, nobody else's
+    // while this call runs -- every user of it synchronises before it returns)
+    int *d_deg = (int *)s->d_f64_tmp;
+    BB_HIP_CHECK(hipMemsetAsync(d_deg, 0, (size_t)s->L.n_pad * sizeof(int), s->stream));
     if (s->n_local > 0) {
 #define BB_DEG(TT, WW)                                                                            \
     BB_HIP_CHECK(bb::launch(unit_degrees_kernel<TT, WW>,                                           \
                             dim3((unsigned)((s->n_local + kDegUnits - 1) / kDegUnits)), dim3(256), 0, \
                             s->stream, (const TT *)s->d_units, s->d_udesc, s->n_local, s->L.n_bins,  \
-                            (int *)buf.p))
+                            d_deg))
         if (s->dtype == BB_F32) BB_DEG(float, true);
         else if (s->wide) BB_DEG(double, true);
         else BB_DEG(double, false);
@@ -1090,7 +1090,7 @@ int bb_solver_degrees(bb_solver *s, int64_t *degree, int64_t n_bins) {
     }
     std::vector<int> host((size_t)n_bins);
     BB_HIP_CHECK(hipStreamSynchronize(s->stream));
-    BB_HIP_CHECK(hipMemcpy(host.data(), buf.p, (size_t)n_bins * sizeof(int), hipMemcpyDeviceToHost));
+    BB_HIP_CHECK(hipMemcpy(host.data(), d_deg, (size_t)n_bins * sizeof(int), hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n_bins; ++i) degree[i] = host[(size_t)i];
     return BB_OK;
 }
