@@ -507,6 +507,11 @@ int launch_grad_t(bb_solver *s, int op, const void *x_in) {
     return BB_OK;
 }
 
+// What the reduce multiplies the summed partials by: 2 for the gradient (SPEC 2.3: the sweep
+// leaves half of it), 1 for a plain sum (the matvec of the spectral start) -- and only a
+// gradient takes the per-bin step factors (fill_reduce_params).
+constexpr double kScaleGradient = 2.0, kScalePlainSum = 1.0;
+
 template <typename T>
 void fill_reduce_params(bb_solver *s, ReduceParams<T> &p, int mode, double lr, double *stress_out,
                         double scale);
@@ -565,8 +570,8 @@ void fill_reduce_params(bb_solver *s, ReduceParams<T> &p, int mode, double lr, d
     p.mode = mode;
     p.stress_slot = s->d_stress_slot;
     p.n_slots = s->n_slots;
-    // (scale 1 is a plain sum -- the matvec, the spectral start's products: never scaled)
-    p.bin_scale = scale == 1.0 ? nullptr : (const T *)s->d_bin_scale;
+    // (a plain sum -- the matvec, the spectral start's products -- is never scaled)
+    p.bin_scale = scale == kScalePlainSum ? nullptr : (const T *)s->d_bin_scale;
     p.map_ptr = s->d_map_ptr;
     p.map_idx = s->d_map_idx;
     p.n_maps = s->n_maps;
@@ -609,10 +614,11 @@ int launch_grad(bb_solver *s, int op = kOpStress, const void *x_in = nullptr) {
     if (!x_in) x_in = s->d_X;
     return BB_BY_LAYOUT(s, launch_grad_t, s, op, x_in);
 }
-int launch_reduce(bb_solver *s, int mode, double lr, double *stress_out, double scale = 2.0) {
+int launch_reduce(bb_solver *s, int mode, double lr, double *stress_out,
+                  double scale = kScaleGradient) {
     return BB_BY_LAYOUT(s, launch_reduce_t, s, mode, lr, stress_out, scale);
 }
-int launch_exchange(bb_solver *s, double lr, double *stress_out, double scale = 2.0) {
+int launch_exchange(bb_solver *s, double lr, double *stress_out, double scale = kScaleGradient) {
     return BB_BY_LAYOUT(s, launch_exchange_t, s, lr, stress_out, scale);
 }
 
@@ -1783,19 +1789,19 @@ int exchange_sum(bb_solver *s) {
         s->sum_target = s->d_exch;
         int rc;
         if (s->peer_fused && s->red_slices > 0) {
-            rc = launch_exchange(s, -1.0, s->d_stress_scalar, 1.0);
+            rc = launch_exchange(s, -1.0, s->d_stress_scalar, kScalePlainSum);
         } else {
-            rc = launch_reduce(s, kReducePeer, 0.0, nullptr, 1.0);
+            rc = launch_reduce(s, kReducePeer, 0.0, nullptr, kScalePlainSum);
             if (rc == BB_OK) rc = launch_peer_receive(s, s->d_exch, -1.0, 0.0, s->d_stress_scalar);
         }
         s->sum_target = nullptr;
         return rc;
     }
     if (s->comm) {
-        BB_TRY(launch_reduce(s, kReduceExchange, 0.0, nullptr, 1.0));
+        BB_TRY(launch_reduce(s, kReduceExchange, 0.0, nullptr, kScalePlainSum));
         return enqueue_allreduce(s);
     }
-    if (s->world == 1) return launch_reduce(s, kReduceExchange, 0.0, nullptr, 1.0);
+    if (s->world == 1) return launch_reduce(s, kReduceExchange, 0.0, nullptr, kScalePlainSum);
     return bb::fail(BB_ERR_STATE, "no exchange between the ranks is set up (bb_solver_peer_connect "
                                   "or bb_solver_comm_init / _attach first)");
 }
@@ -2105,7 +2111,7 @@ int bb_solver_matvec_sq(bb_solver *s, const double *x, double *y) {
     int rc = BB_OK;
     if (e != hipSuccess) rc = bb::fail(BB_ERR_HIP, std::string("bb_solver_matvec_sq: ") + hipGetErrorString(e));
     if (rc == BB_OK) rc = launch_grad(s, kOpMatvec2, d_in);
-    if (rc == BB_OK) rc = launch_reduce(s, kReduceExchange, 0.0, nullptr, 1.0);
+    if (rc == BB_OK) rc = launch_reduce(s, kReduceExchange, 0.0, nullptr, kScalePlainSum);
     if (rc == BB_OK) {
         e = widen(s, s->d_exch, s->d_f64_tmp, n3);
         if (e == hipSuccess)
