@@ -344,7 +344,7 @@ def main():
     tiles = None
     pairs = n * (n - 1) // 2
     lr = 1.0 / (2 * n)
-    blk_scale = None
+    degree_legs = False
     if a.workload == "genome10kb":
         # BASELINE config 5: the dense (n_bins+1)^2 float64 matrix of the reference
         # (blueberry/datatypes.pyx:99) would be 720 GB; the tiles a Hi-C map populates -- each
@@ -355,7 +355,7 @@ def main():
             raise SystemExit("bench.py: --workload genome10kb is a fixed map (strong scaling)")
         tiles, pairs = tiles_from_blocks(n, genome_boundaries(n), a.band_bins, a.dtype)
         lr = 1.0 / (2 * max_degree(n, tiles, a.dtype))
-        blk_scale = True                      # SPEC 2.4.1: a step per bin in the convergence legs
+        degree_legs = True                    # SPEC 2.4.1: a step per bin in the convergence legs
     eng = HipEngine(n, a.dtype, rank=rank, world=world, device=local_rank, tiles=tiles)
     eng.set_wish_from_coords(xs)          # delta_ij = |x*_i - x*_j| generated in HBM
     eng.set_coords(x0)
@@ -466,7 +466,7 @@ def main():
         conv.update(converge_measured(0.0))
         conv_mu.update(converge_measured(a.momentum))
         conv_relaxed.update(converge_measured(a.relax_momentum, a.relax))
-        if blk_scale is not None:
+        if degree_legs:
             # a blocked-sparse map: the same three legs with a step per bin from the map's own
             # degrees (bb_solver_degrees + bb_solver_set_bin_steps = StructureSolver(
             # degree_steps=True); SPEC 2.4.1) -- every chromosome's bins step by their own
