@@ -31,6 +31,17 @@ def step_us(e, reps=60):
     return best * 1e6
 
 
+def split_us(e, reps=40):
+    """(sweep, reduce) by HIP events around the two launches of bb_solver_grad."""
+    e.set_timing(True)
+    for _ in range(reps):
+        e.grad()
+    e.sync()
+    t = e.timing()
+    e.set_timing(False)
+    return t["grad_ms"] * 1e3, t["reduce_ms"] * 1e3
+
+
 def run(workload, world):
     if workload == "dense":
         n, tiles = 50000, None
@@ -44,18 +55,21 @@ def run(workload, world):
     one.set_coords(x0)
     t1 = step_us(one, 20)
     one.close()
-    ts = []
+    ts, parts = [], []
     for r in range(world):
         e = HipEngine(n, "float32", rank=r, world=world, tiles=tiles)
         e.set_wish_from_coords(xs)
         e.set_coords(x0)
         ts.append(step_us(e))
+        parts.append(split_us(e))
         e.close()
     ts = numpy.array(ts)
     print("%s N=%d: one rank %.1f us per step; the %d shares alone: %s us (min %.1f, mean %.1f, max %.1f); "
           "one rank / (%d x slowest share) = %.2f of linear before any exchange"
           % (workload, n, t1, world, " ".join("%.1f" % t for t in ts), ts.min(), ts.mean(), ts.max(),
              world, t1 / (world * ts.max())), flush=True)
+    print("   by events, sweep + reduce per share: %s"
+          % "  ".join("%.1f+%.1f" % p for p in parts), flush=True)
 
 
 if __name__ == "__main__":
