@@ -1249,6 +1249,12 @@ struct ReduceParams {
     // map_idx[map_ptr[m] .. map_ptr[m + 1]) (index < n_waves: stresspart, else stress_slot) --
     // into stress_out[m].  n_maps <= 1: one map, every partial, stress_out[0].
     const T *__restrict__ bin_scale;        // n_pad factors (element o of X belongs to bin o / 3)
+    // peer exchange: which ranks hold units that touch block b (bit r of peer_mask[b]; the same
+    // table on every rank, from the tile list and the partition).  A rank outside a block's
+    // mask has nothing but zeros for it: it does not push them, and nobody waits for or adds
+    // its slot.  nullptr: every rank, every block (BB_PEER_MASK=0).
+    const unsigned *__restrict__ peer_mask;
+    int rank;
     const int *__restrict__ map_ptr;
     const int *__restrict__ map_idx;
     int n_maps;
@@ -1326,7 +1332,7 @@ __global__ __launch_bounds__(kRedWG) void reduce_kernel(ReduceParams<T> p) {
             typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
             constexpr int NV = kRedWG * (int)sizeof(T) / 16;
             __syncthreads();
-            if (tid < NV) {
+            if (tid < NV && (p.peer_mask == nullptr || (p.peer_mask[b] >> p.rank & 1u))) {
                 const vec_t val = ((const vec_t *)push_stage)[tid];
                 for (int q = 0; q < p.n_peers; ++q)
                     ((vec_t *)(p.peer->dst[q] + (int64_t)b * CH + (int64_t)blockIdx.y * kRedWG))[tid] = val;
@@ -1441,7 +1447,7 @@ __global__ __launch_bounds__(128 * S) void reduce_sliced_kernel(ReduceParams<T> 
             typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));
             constexpr int NV = kRedWG * (int)sizeof(T) / 16;
             __syncthreads();
-            if (tid < NV) {
+            if (tid < NV && (p.peer_mask == nullptr || (p.peer_mask[b] >> p.rank & 1u))) {
                 const vec_t val = ((const vec_t *)meet[0])[tid];
                 for (int q = 0; q < p.n_peers; ++q)
                     ((vec_t *)(p.peer->dst[q] + (int64_t)b * CH + (int64_t)blockIdx.y * kRedWG))[tid] = val;
@@ -1568,7 +1574,8 @@ __device__ __forceinline__ T peer_sendable(T v) {
 template <typename T, int NW>
 __device__ __forceinline__ bool peer_wait_sum(const T *base, bool active, int R, int64_t slot_elems,
                                               const PeerTableX<T> *xt, const unsigned long long *my_poison,
-                                              PeerState *state, long long limit, T &sum, double &pair_sum) {
+                                              PeerState *state, long long limit, T &sum, double &pair_sum,
+                                              unsigned mask = ~0u) {
     const int lane = threadIdx.x & 63;
     T v[NW][kMaxPeers];
     bool ok = false;
@@ -1578,11 +1585,13 @@ __device__ __forceinline__ bool peer_wait_sum(const T *base, bool active, int R,
 #pragma unroll
         for (int r = 0; r < kMaxPeers; ++r) {
             if (r < R) {
+                const bool sends = (mask >> r & 1u) != 0;        // (wave-uniform)
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
-                    v[w][r] = active ? __hip_atomic_load(base + (int64_t)r * slot_elems + w, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_SYSTEM)
-                                     : T(0);
+                    v[w][r] = (active && sends)
+                                  ? __hip_atomic_load(base + (int64_t)r * slot_elems + w, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_SYSTEM)
+                                  : T(0);
                     missing |= peer_word_empty(v[w][r]);
                 }
             }
@@ -1615,7 +1624,7 @@ __device__ __forceinline__ bool peer_wait_sum(const T *base, bool active, int R,
         if (r < R) {
             s0 += v[0][r];
             if (NW > 1) s2 += (double)v[0][r] + (double)v[NW - 1][r];
-            if (active) {
+            if (active && (mask >> r & 1u)) {
 #pragma unroll
                 for (int w = 0; w < NW; ++w)
                     __hip_atomic_store(const_cast<T *>(base) + (int64_t)r * slot_elems + w,
@@ -1677,11 +1686,13 @@ __global__ __launch_bounds__(128 * S) void reduce_exchange_kernel(
 #pragma unroll
         for (int q = 1; q < S; ++q) tot += meet[q][el];
         const T mine = peer_sendable(p.bin_scale ? p.bin_scale[o / 3] * (p.scale * tot) : p.scale * tot);
-        for (int q = 0; q < R; ++q)
-            __hip_atomic_store(xt->dst[q] + o, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned mask = p.peer_mask ? p.peer_mask[b] : ~0u;
+        if (mask >> p.rank & 1u)
+            for (int q = 0; q < R; ++q)
+                __hip_atomic_store(xt->dst[q] + o, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         T g;
         double unused;
-        if (peer_wait_sum<T, 1>(arena + o, true, R, slot_elems, xt, my_poison, state, limit, g, unused)) {
+        if (peer_wait_sum<T, 1>(arena + o, true, R, slot_elems, xt, my_poison, state, limit, g, unused, mask)) {
             // SPEC 2.4: V <- mu V - lr g ; X <- X + V, g = the sum over ranks in rank order
             const T vv = p.mu * vo - p.lr * g;
             p.V[o] = vv;
@@ -1727,7 +1738,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void peer_receive_kernel(
     T *__restrict__ X, T *__restrict__ V, const T *arena, const unsigned long long *flags,
     unsigned long long *const *poison_flags, int world, int64_t slot_elems, int64_t n3, T lr, T mu,
-    double *stress_out, unsigned long long seq, PeerState *state, long long limit) {
+    double *stress_out, unsigned long long seq, PeerState *state, long long limit,
+    const unsigned *__restrict__ peer_mask, int ch) {
     const int tid = threadIdx.x;
     __shared__ int go;
     if (tid < 64) {
@@ -1795,6 +1807,12 @@ __global__ __launch_bounds__(256) void peer_receive_kernel(
         T g[EPT];
 #pragma unroll
         for (int q = 0; q < EPT; ++q) g[q] = T(0);
+        unsigned mk[EPT];                       // the ranks that sent something for the element's block
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int64_t e = base + q * stride;
+            mk[q] = (peer_mask != nullptr && e < n3) ? peer_mask[e / ch] : ~0u;
+        }
         for (int r0 = 0; r0 < world; r0 += 8) {
             T v[EPT][8];
 #pragma unroll
@@ -1802,7 +1820,7 @@ __global__ __launch_bounds__(256) void peer_receive_kernel(
                 const int64_t e = base + q * stride;
 #pragma unroll
                 for (int p = 0; p < 8; ++p)
-                    v[q][p] = (e < n3 && r0 + p < world)
+                    v[q][p] = (e < n3 && r0 + p < world && (mk[q] >> (r0 + p) & 1u))
                                   ? __hip_atomic_load(arena + (r0 + p) * slot_elems + e,
                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
                                   : T(0);

@@ -460,6 +460,53 @@ def test_rccl_single_rank_device_path():
     assert "NCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("form", ["one launch", "two launches"])
+def test_peer_exchange_contributor_mask_changes_no_bit(form, monkeypatch):
+    """A rank sends a block's partial only if its units touch the block (the table every rank
+    derives from the tile list and the partition): the zeros it used to push are neither sent
+    nor waited for nor added -- and not one bit of the result changes (BB_PEER_MASK=0 is the
+    form that sends everything).  Three ranks on a dense map, where rank 0 touches the first
+    tile columns only, and on a blocked-sparse one."""
+    monkeypatch.setenv("BB_PEER_TIMEOUT_MS", "20000")
+    monkeypatch.setenv("BB_PEER_FUSED", "1" if form == "one launch" else "0")
+    from blueberry_amd.solver import tiles_from_blocks
+    from tests import _oracle
+    import ctypes
+    from blueberry_amd import _lib
+    from blueberry_amd.solver import HipEngine
+    lib = _lib.load()
+    world, k = 3, 5
+    for n, tiles in ((2600, None), (3100, tiles_from_blocks(3100, [0, 1500, 2300, 3100], 100, "float32")[0])):
+        xs = _oracle.random_walk(n)
+        x0 = _oracle.noisy_init(xs)
+        lr = 1.0 / (2 * n)
+        out = {}
+        for setting in ("1", "0"):
+            monkeypatch.setenv("BB_PEER_MASK", setting)
+            engs = [HipEngine(n, "float32", rank=r, world=world, tiles=tiles) for r in range(world)]
+            blobs = []
+            for e in engs:
+                buf = ctypes.create_string_buffer(_lib.BB_PEER_HANDLE_BYTES)
+                _lib.check(lib.bb_solver_peer_export(e._h, buf), "export")
+                blobs.append(buf.raw)
+            for e in engs:
+                _lib.check(lib.bb_solver_peer_connect(e._h, b"".join(blobs)), "connect")
+                e.set_wish_from_coords(xs)
+                e.set_coords(x0)
+                e.set_momentum(0.3)
+            for _ in range(k):
+                for e in engs:
+                    e.iterate_peer(1, lr)
+            for e in engs:
+                assert e.peer_status() == 0
+            out[setting] = [(e.get_coords(), e.stress_history()) for e in engs]
+            for e in engs:
+                e.close()
+        for (Xa, ha), (Xb, hb) in zip(out["1"], out["0"]):
+            assert numpy.array_equal(Xa, Xb) and numpy.array_equal(ha, hb)
+        assert all(numpy.array_equal(X, out["1"][0][0]) for X, _ in out["1"][1:])
+
+
 def test_eight_ranks_over_the_peer_exchange_in_one_process():
     """World size 8 -- what the scaling run uses -- rehearsed on one GPU: eight ranks of ONE
     process (more than the six processes a box allows on its GPU), arenas connected directly,
